@@ -1,0 +1,171 @@
+/*
+ * srx -- MI355X (gfx950) kernels for the MFCC + diagonal-Gaussian HMM hot path.
+ *
+ * C ABI of libsrx.so.  The reference (Tejashreenk/Speech-Recognition) is pure
+ * Python and has no FFI of its own for this path; each entry point below names
+ * the reference function(s) whose arithmetic it replaces.  A Python binding is
+ * a ctypes stub over exactly these symbols.
+ *
+ * Conventions
+ *   - every pointer argument except `cfg`, `models`, `priors` and out-handles
+ *     is a DEVICE pointer owned by the caller;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all
+ *     entry points enqueue work on it and return without synchronising;
+ *   - return value: 0 on success, negative srx_status on failure, the message
+ *     is available from srx_last_error() (thread-local);
+ *   - dtype selects the arithmetic and the element type of X / audio / feature
+ *     buffers: SRX_F32 is the fast path, SRX_F64 the validation ("parity")
+ *     path.  Model parameters, scores, statistics are always double.
+ *   - utterances are ragged: `utt_offsets` holds U+1 int64 frame (or sample)
+ *     offsets into the packed buffer, offsets[0] == 0 and offsets[U] ==
+ *     n_frames (n_samples), which the caller also passes by value so that the
+ *     library can size its scratch without reading device memory.
+ */
+#ifndef SRX_H
+#define SRX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct srx_context* srx_handle_t;
+typedef struct srx_mfcc_plan* srx_mfcc_plan_t;
+
+enum srx_dtype { SRX_F32 = 0, SRX_F64 = 1 };
+
+enum srx_status {
+    SRX_OK = 0,
+    SRX_EINVAL = -1,       /* bad shape / argument (the reference raises ValueError) */
+    SRX_EHIP = -2,         /* a HIP runtime call failed */
+    SRX_ENOMEM = -3,       /* workspace allocation failed */
+    SRX_EUNSUPPORTED = -4  /* shape outside what the kernels are built for */
+};
+
+enum srx_mstep_mode {
+    SRX_MSTEP_FULL = 0,             /* do_mstep, my_hmmlearn/hmm.py:165-184 */
+    SRX_MSTEP_TRANSITIONS_ONLY = 1  /* do_em_mstep only (what fit() calls, hmm.py:213) */
+};
+
+/* A bank of n_models HMMs that share n_states and n_features.  Device pointers,
+ * C-contiguous doubles: attributes startprob_ / transmat_ / means_ / _covars_
+ * of MyGaussianHMM (my_hmmlearn/hmm.py:116-134). */
+typedef struct {
+    int32_t n_models;
+    int32_t n_states;
+    int32_t n_features;
+    double* startprob; /* [n_models, S]    */
+    double* transmat;  /* [n_models, S, S] */
+    double* means;     /* [n_models, S, D] */
+    double* covars;    /* [n_models, S, D] */
+} srx_models_t;
+
+/* Constructor defaults of MyGaussianHMM, my_hmmlearn/hmm.py:75-82. */
+typedef struct {
+    double startprob_prior; /* 1.0  */
+    double transmat_prior;  /* 1.0  */
+    double means_prior;     /* 0.0  */
+    double means_weight;    /* 0.0  */
+    double covars_prior;    /* 1e-2 */
+    double covars_weight;   /* 1.0  */
+} srx_priors_t;
+
+/* Front-end constants.  The reference fixes nfft=1024, n_mel=26,
+ * mel_sample_rate=16000 (mfcc.py:25,40,47), n_ceps=13 (mfcc.py:78),
+ * delta_order=1, delta_n=2 (mfcc.py:88,165), log_mult=20 (mfcc.py:44) and
+ * z-scores every utterance (HMM_final.py:22). frame_len/hop are
+ * int(0.025*sr) / int(0.01*sr) (mfcc.py:18-19). */
+typedef struct {
+    int32_t sample_rate;
+    int32_t frame_len;
+    int32_t hop;
+    int32_t nfft;            /* power of two, 64..4096 */
+    int32_t n_mel;           /* <= 128 */
+    int32_t mel_sample_rate;
+    int32_t n_ceps;          /* <= n_mel, <= 32 */
+    int32_t delta_order;     /* 0, 1 or 2 */
+    int32_t delta_n;         /* regression half-width, reference: 2 */
+    int32_t zscore;          /* 0 / 1 */
+    double log_mult;         /* multiplies log10(mel energy) */
+} srx_mfcc_cfg_t;
+
+/* ---- library / context ------------------------------------------------- */
+int srx_version(void);
+const char* srx_last_error(void);
+/* One context per GPU / rank; owns the scratch workspace the kernels need. */
+int srx_create(int device, srx_handle_t* out);
+int srx_destroy(srx_handle_t h);
+/* Bytes of scratch currently held by the context (diagnostics). */
+int64_t srx_workspace_bytes(srx_handle_t h);
+
+/* Doubles per model in a packed statistics record:
+ * [nobs, logprob, start(S), trans(S*S), post(S), obs(S*D), obs2(S*D)]
+ * = the dict of initialize_sufficient_statistics (hmm.py:224-235) plus the
+ * summed log-probability do_estep returns (hmm.py:433). */
+int64_t srx_stats_size(int32_t n_states, int32_t n_features);
+
+/* ---- front-end: replaces mfcc.compute_mfcc / delta / the concat in
+ * calculate_mfcc_for_onerecording (mfcc.py:82-96, :141-169) and the
+ * StandardScaler of extract_mfcc_calc (HMM_final.py:18-23) ---------------- */
+int srx_mfcc_plan_create(srx_handle_t h, const srx_mfcc_cfg_t* cfg, srx_mfcc_plan_t* out);
+int srx_mfcc_plan_destroy(srx_mfcc_plan_t plan);
+/* Frames produced for an utterance of n_samples (after the delta trim). */
+int64_t srx_mfcc_out_frames(const srx_mfcc_cfg_t* cfg, int64_t n_samples);
+/* audio: packed samples (dtype), sample_offsets[U+1]; out_feats: packed
+ * [sum frames, n_ceps*(1+delta_order)] (dtype), frame_offsets[U+1] must hold
+ * the cumulative srx_mfcc_out_frames of every utterance. */
+int srx_mfcc_batch(srx_handle_t h, srx_mfcc_plan_t plan, const void* audio, int dtype,
+                   const int64_t* sample_offsets, int64_t n_utts, int64_t n_samples,
+                   void* out_feats, const int64_t* frame_offsets, void* stream);
+/* The dense (n_mel, nfft/2+1) filter matrix the plan is built from, written to
+ * HOST memory: mel_filterbank, mfcc.py:47-61 (diagnostic, no GPU needed). */
+int srx_mfcc_filterbank_host(const srx_mfcc_cfg_t* cfg, double* out_dense);
+
+/* ---- emissions: _log_multivariate_normal_density_diag, hmm.py:154-163 ----
+ * out[f, m*S + s] for every frame and every state of every model (dtype). */
+int srx_emission_loglik(srx_handle_t h, const void* X, int dtype, int64_t n_frames,
+                        const srx_models_t* models, void* out, void* stream);
+
+/* ---- scoring: score / score_scaling + utils.forward_scaling,
+ * hmm.py:186-196, :308-323, utils.py:132-150; the per-word loop of recognize
+ * (HMM_final.py:49-52) is the model axis.  out_scores[u, m] (double) is the
+ * forward log-probability of utterance u under model m. */
+int srx_forward_score(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
+                      int64_t n_utts, int64_t n_frames, const srx_models_t* models,
+                      double* out_scores, void* stream);
+/* Same contract, always through the shape-generic kernels (any S <= 64, any D);
+ * srx_forward_score uses them only for shapes without a matrix-core kernel. */
+int srx_forward_score_generic(srx_handle_t h, const void* X, int dtype,
+                              const int64_t* utt_offsets, int64_t n_utts, int64_t n_frames,
+                              const srx_models_t* models, double* out_scores, void* stream);
+
+/* ---- decoding: utils.viterbi, utils.py:243-266 (decode, hmm.py:357-373, is
+ * broken in the reference).  utt_model[u] (int32, may be NULL = model 0)
+ * selects the model; out_path[f] int32 state per frame, out_logprob[u]. */
+int srx_viterbi(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
+                int64_t n_utts, int64_t n_frames, const int32_t* utt_model,
+                const srx_models_t* models, int32_t* out_path, double* out_logprob,
+                void* stream);
+
+/* ---- Baum-Welch E-step: do_estep + fit_scaling +
+ * accumulate_sufficient_statistics(_scaling), hmm.py:419-433, :330-354,
+ * :237-253, utils.py:132-218.  Every utterance contributes to the record of
+ * its model utt_model[u] (NULL = model 0).  utt_order (NULL = 0..U-1) is the
+ * order utterances are visited in; a permutation that groups the utterances
+ * of one model together makes the accumulation cheaper and changes nothing
+ * but the summation order.  out_stats[n_models, stats_size] is overwritten. */
+int srx_estep_stats(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
+                    int64_t n_utts, int64_t n_frames, const int32_t* utt_model,
+                    const int64_t* utt_order, const srx_models_t* models, double* out_stats,
+                    void* stream);
+
+/* ---- M-step: do_em_mstep (hmm.py:435-451) and do_mstep (hmm.py:165-184),
+ * applied in place to every model of the bank from its statistics record. */
+int srx_mstep(srx_handle_t h, const double* stats, const srx_priors_t* priors, int mode,
+              const srx_models_t* models, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRX_H */

@@ -1,0 +1,197 @@
+// C ABI of libsrx: context, argument checks and dispatch to the kernels.
+#include "srx_internal.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+void srx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int srx_ws_ensure(srx_context* h, int slot, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    if (h->ws_bytes[slot] < bytes) {
+        if (h->ws[slot]) {
+            // hipFree synchronises the device, so queued kernels that still
+            // read the old buffer have finished.
+            SRX_HIP(hipFree(h->ws[slot]));
+            h->ws[slot] = nullptr;
+            h->ws_bytes[slot] = 0;
+        }
+        const size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&h->ws[slot], want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            srx_set_error("workspace slot %d: hipMalloc(%zu) failed: %s", slot, want,
+                          hipGetErrorString(e));
+            return SRX_ENOMEM;
+        }
+        h->ws_bytes[slot] = want;
+    }
+    *out = h->ws[slot];
+    return SRX_OK;
+}
+
+namespace {
+
+int check_models(const srx_models_t* m, const char* who) {
+    SRX_REQUIRE(m != nullptr, "%s: models is NULL", who);
+    SRX_REQUIRE(m->n_models >= 1 && m->n_states >= 1 && m->n_features >= 1,
+                "%s: Shape mismatch (n_models=%d n_states=%d n_features=%d)", who, m->n_models,
+                m->n_states, m->n_features);
+    SRX_REQUIRE(m->n_states <= 64, "%s: n_states %d > 64 is not supported", who, m->n_states);
+    SRX_REQUIRE(m->startprob && m->transmat && m->means && m->covars,
+                "%s: NULL model parameter array", who);
+    return SRX_OK;
+}
+
+int check_common(srx_handle_t h, const void* X, int dtype, int64_t n_utts, int64_t n_frames,
+                 const void* off, const char* who) {
+    SRX_REQUIRE(h != nullptr, "%s: NULL context", who);
+    SRX_REQUIRE(dtype == SRX_F32 || dtype == SRX_F64, "%s: unknown dtype %d", who, dtype);
+    SRX_REQUIRE(n_utts >= 0 && n_frames >= 0, "%s: negative size", who);
+    SRX_REQUIRE(n_utts == 0 || off != nullptr, "%s: NULL utterance offsets", who);
+    SRX_REQUIRE(n_frames == 0 || X != nullptr, "%s: NULL X", who);
+    return SRX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int srx_version(void) { return 100; }
+
+const char* srx_last_error(void) { return g_err; }
+
+int srx_create(int device, srx_handle_t* out) {
+    SRX_REQUIRE(out != nullptr, "srx_create: NULL out");
+    int n = 0;
+    SRX_HIP(hipGetDeviceCount(&n));
+    SRX_REQUIRE(device >= 0 && device < n, "srx_create: device %d out of range (%d visible)",
+                device, n);
+    SRX_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SRX_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        srx_set_error("srx_create: device %d is %s; this library is built for gfx950 only", device,
+                      prop.gcnArchName);
+        return SRX_EUNSUPPORTED;
+    }
+    srx_context* h = new srx_context();
+    memset(h, 0, sizeof(*h));
+    h->device = device;
+    h->n_cu = prop.multiProcessorCount;
+    *out = h;
+    return SRX_OK;
+}
+
+int srx_destroy(srx_handle_t h) {
+    if (!h) return SRX_OK;
+    (void)hipSetDevice(h->device);
+    for (int i = 0; i < WS_NUM; ++i)
+        if (h->ws[i]) (void)hipFree(h->ws[i]);
+    delete h;
+    return SRX_OK;
+}
+
+int64_t srx_workspace_bytes(srx_handle_t h) {
+    if (!h) return 0;
+    int64_t s = 0;
+    for (int i = 0; i < WS_NUM; ++i) s += (int64_t)h->ws_bytes[i];
+    return s;
+}
+
+int64_t srx_stats_size(int32_t n_states, int32_t n_features) {
+    return srx_stats_layout(n_states, n_features).size;
+}
+
+int srx_emission_loglik(srx_handle_t h, const void* X, int dtype, int64_t n_frames,
+                        const srx_models_t* models, void* out, void* stream) {
+    int rc = check_common(h, X, dtype, 0, n_frames, nullptr, "srx_emission_loglik");
+    if (rc) return rc;
+    if ((rc = check_models(models, "srx_emission_loglik"))) return rc;
+    if (n_frames == 0) return SRX_OK;
+    SRX_REQUIRE(out != nullptr, "srx_emission_loglik: NULL out");
+    SRX_HIP(hipSetDevice(h->device));
+    return srx_generic_emission(h, X, dtype, n_frames, models, out, (hipStream_t)stream);
+}
+
+int srx_forward_score(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
+                      int64_t n_utts, int64_t n_frames, const srx_models_t* models,
+                      double* out_scores, void* stream) {
+    int rc = check_common(h, X, dtype, n_utts, n_frames, utt_offsets, "srx_forward_score");
+    if (rc) return rc;
+    if ((rc = check_models(models, "srx_forward_score"))) return rc;
+    if (n_utts == 0) return SRX_OK;
+    SRX_REQUIRE(out_scores != nullptr, "srx_forward_score: NULL out_scores");
+    SRX_HIP(hipSetDevice(h->device));
+    if (dtype == SRX_F32) {
+        rc = srx_mfma_score(h, X, utt_offsets, n_utts, n_frames, models, out_scores,
+                            (hipStream_t)stream);
+        if (rc != SRX_EUNSUPPORTED) return rc;
+    }
+    return srx_generic_score(h, X, dtype, utt_offsets, n_utts, n_frames, models, out_scores,
+                             (hipStream_t)stream);
+}
+
+int srx_forward_score_generic(srx_handle_t h, const void* X, int dtype,
+                              const int64_t* utt_offsets, int64_t n_utts, int64_t n_frames,
+                              const srx_models_t* models, double* out_scores, void* stream) {
+    int rc = check_common(h, X, dtype, n_utts, n_frames, utt_offsets, "srx_forward_score_generic");
+    if (rc) return rc;
+    if ((rc = check_models(models, "srx_forward_score_generic"))) return rc;
+    if (n_utts == 0) return SRX_OK;
+    SRX_REQUIRE(out_scores != nullptr, "srx_forward_score_generic: NULL out_scores");
+    SRX_HIP(hipSetDevice(h->device));
+    return srx_generic_score(h, X, dtype, utt_offsets, n_utts, n_frames, models, out_scores,
+                             (hipStream_t)stream);
+}
+
+int srx_viterbi(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
+                int64_t n_utts, int64_t n_frames, const int32_t* utt_model,
+                const srx_models_t* models, int32_t* out_path, double* out_logprob,
+                void* stream) {
+    int rc = check_common(h, X, dtype, n_utts, n_frames, utt_offsets, "srx_viterbi");
+    if (rc) return rc;
+    if ((rc = check_models(models, "srx_viterbi"))) return rc;
+    if (n_utts == 0) return SRX_OK;
+    SRX_REQUIRE(out_logprob != nullptr && (n_frames == 0 || out_path != nullptr),
+                "srx_viterbi: NULL output");
+    SRX_HIP(hipSetDevice(h->device));
+    return srx_generic_viterbi(h, X, dtype, utt_offsets, n_utts, n_frames, utt_model, models,
+                               out_path, out_logprob, (hipStream_t)stream);
+}
+
+int srx_estep_stats(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
+                    int64_t n_utts, int64_t n_frames, const int32_t* utt_model,
+                    const int64_t* utt_order, const srx_models_t* models, double* out_stats,
+                    void* stream) {
+    int rc = check_common(h, X, dtype, n_utts, n_frames, utt_offsets, "srx_estep_stats");
+    if (rc) return rc;
+    if ((rc = check_models(models, "srx_estep_stats"))) return rc;
+    SRX_REQUIRE(out_stats != nullptr, "srx_estep_stats: NULL out_stats");
+    SRX_HIP(hipSetDevice(h->device));
+    return srx_generic_estep(h, X, dtype, utt_offsets, n_utts, n_frames, utt_model, utt_order,
+                             models, out_stats, (hipStream_t)stream);
+}
+
+int srx_mstep(srx_handle_t h, const double* stats, const srx_priors_t* priors, int mode,
+              const srx_models_t* models, void* stream) {
+    SRX_REQUIRE(h != nullptr && stats != nullptr && priors != nullptr, "srx_mstep: NULL argument");
+    SRX_REQUIRE(mode == SRX_MSTEP_FULL || mode == SRX_MSTEP_TRANSITIONS_ONLY,
+                "srx_mstep: unknown mode %d", mode);
+    int rc = check_models(models, "srx_mstep");
+    if (rc) return rc;
+    SRX_HIP(hipSetDevice(h->device));
+    return srx_generic_mstep(h, stats, priors, mode, models, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,684 @@
+// Shape-generic HMM kernels: any number of models, S <= 64 states, any feature
+// count, float or double arithmetic.  This is the validation ("parity") path
+// in double and the fallback for shapes the matrix-core kernels do not cover.
+//
+// Decomposition (all ragged over utterances):
+//   prep      model tables in the compute dtype (means, -1/(2 var), constants, log A)
+//   emission  log N(x_t; mu_s, var_s) for every (frame, state)        [HBM/VALU]
+//   chain     one sub-wave of SP lanes (SP = next pow2 >= S) per (utterance, model):
+//             lane j owns state j, cross-lane traffic by width-SP shuffles
+//             - score:   scaled forward, log-prob accumulated in double
+//             - fb:      forward, backward, posteriors, xi row sums
+//             - viterbi: max-plus forward with back-pointers + back-trace
+//   stats     gamma^T [X, X^2] per model, per-workgroup partials then a fixed-order sum
+//
+// Scaling.  The reference exponentiates the log-densities and rescales the
+// forward variables by 1/sum (my_hmmlearn/utils.py:139-147).  Here every frame
+// is first shifted by its largest log-density m_t (b~ = exp(ll - m_t)); the
+// scaled lattices are unchanged, the frame's scale becomes c~_t = c_t exp(m_t)
+// and log P = sum_t (m_t - log c~_t), so nothing underflows in float.
+#include "srx_internal.h"
+
+#include <math.h>
+
+__global__ void srx_fill_slices(int64_t* offs, int64_t n_slices, int64_t slice, int64_t n_frames);
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr double kTiny = 2.2250738585072014e-308;  // np.finfo(float).tiny, hmm.py:159
+
+template <typename T>
+struct Tables {
+    const T* mu;     // [M,S,D]
+    const T* hinv;   // [M,S,D]  -0.5 / var
+    const T* cst;    // [M,S]    -0.5 (D log 2pi + sum log var)
+    const T* A;      // [M,S,S]
+    const T* pi;     // [M,S]
+    const T* logA;   // [M,S,S]
+    const T* logpi;  // [M,S]
+};
+
+template <typename T>
+size_t tables_bytes(int M, int S, int D) {
+    return sizeof(T) * ((size_t)M * S * D * 2 + (size_t)M * S * 3 + (size_t)M * S * S * 2);
+}
+
+template <typename T>
+Tables<T> carve_tables(void* base, int M, int S, int D) {
+    T* p = (T*)base;
+    Tables<T> t;
+    t.mu = p;      p += (size_t)M * S * D;
+    t.hinv = p;    p += (size_t)M * S * D;
+    t.cst = p;     p += (size_t)M * S;
+    t.A = p;       p += (size_t)M * S * S;
+    t.pi = p;      p += (size_t)M * S;
+    t.logA = p;    p += (size_t)M * S * S;
+    t.logpi = p;
+    return t;
+}
+
+template <typename T>
+__global__ void prep_kernel(srx_models_t md, T* mu, T* hinv, T* cst, T* A, T* pi, T* logA,
+                            T* logpi) {
+    const int M = md.n_models, S = md.n_states, D = md.n_features;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nth = gridDim.x * blockDim.x;
+    for (int i = tid; i < M * S * D; i += nth) {
+        double v = fmax(md.covars[i], kTiny);
+        mu[i] = (T)md.means[i];
+        hinv[i] = (T)(-0.5 / v);
+    }
+    for (int i = tid; i < M * S; i += nth) {
+        double acc = 0.0;
+        for (int d = 0; d < D; ++d) acc += log(fmax(md.covars[(size_t)i * D + d], kTiny));
+        cst[i] = (T)(-0.5 * (D * 1.8378770664093453 + acc));
+        pi[i] = (T)md.startprob[i];
+        logpi[i] = (T)log(md.startprob[i]);
+    }
+    for (int i = tid; i < M * S * S; i += nth) {
+        A[i] = (T)md.transmat[i];
+        logA[i] = (T)log(md.transmat[i]);
+    }
+}
+
+// One workgroup per utterance (grid-stride).  sel < 0: all models, columns
+// m*S+s; otherwise only the utterance's own model (utt_model or model 0).
+template <typename T>
+__global__ void emission_kernel(const T* __restrict__ X, const int64_t* __restrict__ off,
+                                int64_t U, const int32_t* __restrict__ utt_model, int all_models,
+                                int M, int S, int D, Tables<T> tb, T* __restrict__ out) {
+    const int NC = all_models ? M * S : S;
+    for (int64_t u = blockIdx.x; u < U; u += gridDim.x) {
+        const int64_t f0 = off[u];
+        const int64_t n = (off[u + 1] - f0) * NC;
+        const int mbase = all_models ? 0 : (utt_model ? utt_model[u] : 0);
+        for (int64_t idx = threadIdx.x; idx < n; idx += blockDim.x) {
+            const int64_t f = f0 + idx / NC;
+            const int c = (int)(idx % NC) + mbase * S;
+            const T* x = X + f * D;
+            const T* mu = tb.mu + (size_t)c * D;
+            const T* hi = tb.hinv + (size_t)c * D;
+            T acc = 0;
+            for (int d = 0; d < D; ++d) {
+                T df = x[d] - mu[d];
+                acc += df * df * hi[d];
+            }
+            out[f * NC + (c - mbase * S)] = acc + tb.cst[c];
+        }
+    }
+}
+
+template <typename T, int SP>
+__device__ __forceinline__ T sub_sum(T v) {
+#pragma unroll
+    for (int o = SP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, SP);
+    return v;
+}
+template <typename T, int SP>
+__device__ __forceinline__ T sub_max(T v) {
+#pragma unroll
+    for (int o = SP / 2; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, SP));
+    return v;
+}
+
+template <typename T> __device__ __forceinline__ T neg_inf();
+template <> __device__ __forceinline__ float neg_inf<float>() { return -INFINITY; }
+template <> __device__ __forceinline__ double neg_inf<double>() { return -(double)INFINITY; }
+
+// Scaled forward over one chain per sub-wave.  loglik row stride is NC.
+template <typename T, int SP>
+__global__ void score_chain_kernel(const T* __restrict__ loglik, const int64_t* __restrict__ off,
+                                   int64_t U, int M, int S, Tables<T> tb,
+                                   double* __restrict__ out) {
+    const int j = threadIdx.x % SP;
+    const int64_t sub = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SP;
+    const int64_t nsub = (int64_t)gridDim.x * blockDim.x / SP;
+    const int NC = M * S;
+    for (int64_t chain = sub; chain < U * M; chain += nsub) {
+        const int64_t u = chain / M;
+        const int m = (int)(chain % M);
+        const int64_t f0 = off[u];
+        const int T_len = (int)(off[u + 1] - f0);
+        T acol[SP];
+#pragma unroll
+        for (int i = 0; i < SP; ++i)
+            acol[i] = (i < S && j < S) ? tb.A[((size_t)m * S + i) * S + j] : (T)0;
+        const T pij = j < S ? tb.pi[m * S + j] : (T)0;
+        const T* ll = loglik + f0 * NC + m * S + j;
+        T alpha = 0;
+        double lp = 0.0;
+        for (int t = 0; t < T_len; ++t) {
+            const T l = j < S ? ll[(int64_t)t * NC] : neg_inf<T>();
+            const T mx = sub_max<T, SP>(l);
+            const T b = j < S ? exp(l - mx) : (T)0;
+            T a;
+            if (t == 0) {
+                a = pij * b;
+            } else {
+                a = 0;
+#pragma unroll
+                for (int i = 0; i < SP; ++i) a += __shfl(alpha, i, SP) * acol[i];
+                a *= b;
+            }
+            const T c = sub_sum<T, SP>(a);
+            lp += (double)mx + log((double)c);
+            alpha = a / c;
+        }
+        if (j == 0) out[chain] = lp;
+    }
+}
+
+// Forward-backward for the utterance's own model.  loglik row stride is S.
+// Writes posteriors into `lat` (which first holds the forward lattice), and
+// accumulates start / xi / log-prob / nobs into LDS, then one partial record
+// per workgroup: partial[blockIdx][M][S*S + S + 2] = {xi, start, logprob, nobs}.
+template <typename T, int SP>
+__global__ void fb_chain_kernel(const T* __restrict__ loglik, const int64_t* __restrict__ off,
+                                int64_t U, const int32_t* __restrict__ utt_model,
+                                const int64_t* __restrict__ utt_order, int M, int S,
+                                Tables<T> tb, T* __restrict__ lat, T* __restrict__ scale,
+                                double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) double acc[];
+    const int P = S * S + S + 2;
+    for (int i = threadIdx.x; i < M * P; i += blockDim.x) acc[i] = 0.0;
+    __syncthreads();
+
+    const int j = threadIdx.x % SP;
+    const int64_t sub = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SP;
+    const int64_t nsub = (int64_t)gridDim.x * blockDim.x / SP;
+    for (int64_t k = sub; k < U; k += nsub) {
+        const int64_t u = utt_order ? utt_order[k] : k;
+        const int m = utt_model ? utt_model[u] : 0;
+        const int64_t f0 = off[u];
+        const int T_len = (int)(off[u + 1] - f0);
+        if (T_len <= 0) continue;
+        T acol[SP], arow[SP];
+#pragma unroll
+        for (int i = 0; i < SP; ++i) {
+            acol[i] = (i < S && j < S) ? tb.A[((size_t)m * S + i) * S + j] : (T)0;
+            arow[i] = (i < S && j < S) ? tb.A[((size_t)m * S + j) * S + i] : (T)0;
+        }
+        const T pij = j < S ? tb.pi[m * S + j] : (T)0;
+        const T* ll = loglik + f0 * S + j;
+        T* la = lat + f0 * S + j;
+        T* sc = scale + f0;
+        // ---- forward
+        T alpha = 0;
+        double lp = 0.0;
+        for (int t = 0; t < T_len; ++t) {
+            const T l = j < S ? ll[(int64_t)t * S] : neg_inf<T>();
+            const T mx = sub_max<T, SP>(l);
+            const T b = j < S ? exp(l - mx) : (T)0;
+            T a;
+            if (t == 0) {
+                a = pij * b;
+            } else {
+                a = 0;
+#pragma unroll
+                for (int i = 0; i < SP; ++i) a += __shfl(alpha, i, SP) * acol[i];
+                a *= b;
+            }
+            const T c = sub_sum<T, SP>(a);
+            lp += (double)mx + log((double)c);
+            const T ci = (T)1 / c;
+            alpha = a * ci;
+            if (j < S) la[(int64_t)t * S] = alpha;
+            if (j == 0) sc[t] = ci;
+        }
+        // ---- backward, posteriors, xi
+        T xi[SP];
+#pragma unroll
+        for (int i = 0; i < SP; ++i) xi[i] = 0;
+        T bb = 0;      // b~_{t+1}[j] * beta'_{t+1}[j]
+        T gamma0 = 0;
+        for (int t = T_len - 1; t >= 0; --t) {
+            const T al = j < S ? la[(int64_t)t * S] : (T)0;
+            const T ci = sc[t];
+            T beta;
+            if (t == T_len - 1) {
+                beta = ci;
+            } else {
+                T s = 0;
+#pragma unroll
+                for (int i = 0; i < SP; ++i) {
+                    const T w = arow[i] * __shfl(bb, i, SP);
+                    s += w;
+                    xi[i] += al * w;
+                }
+                beta = s * ci;
+            }
+            T g = al * beta;
+            T gs = sub_sum<T, SP>(g);
+            if (gs == (T)0) gs = (T)1;   // utils.normalize: zero rows divide by 1
+            g = g / gs;
+            if (j < S) la[(int64_t)t * S] = g;
+            const T l = j < S ? ll[(int64_t)t * S] : neg_inf<T>();
+            const T mx = sub_max<T, SP>(l);
+            const T b = j < S ? exp(l - mx) : (T)0;
+            bb = b * beta;
+            gamma0 = g;
+        }
+        if (j < S) {
+            double* a = acc + (size_t)m * P;
+            if (T_len > 1)
+                for (int i = 0; i < S; ++i) atomicAdd(&a[j * S + i], (double)xi[i]);
+            atomicAdd(&a[S * S + j], (double)gamma0);
+            if (j == 0) {
+                atomicAdd(&a[S * S + S], lp);
+                atomicAdd(&a[S * S + S + 1], 1.0);
+            }
+        }
+    }
+    __syncthreads();
+    double* dst = partial + (size_t)blockIdx.x * M * P;
+    for (int i = threadIdx.x; i < M * P; i += blockDim.x) dst[i] = acc[i];
+}
+
+// post / obs / obs2: each workgroup walks a contiguous slice of the processing
+// order; thread owns (s,d) pairs and keeps their sums in registers while the
+// model does not change, then adds them to its own slice of `partial`
+// [gridDim][M][S + 2 S D].
+template <typename T, int SLOTS>
+__global__ void obs_stats_kernel(const T* __restrict__ X, const T* __restrict__ gamma,
+                                 const int64_t* __restrict__ off, int64_t U,
+                                 const int32_t* __restrict__ utt_model,
+                                 const int64_t* __restrict__ utt_order, int M, int S, int D,
+                                 double* __restrict__ partial) {
+    const int SD = S * D;
+    const int Q = S + 2 * SD;
+    double* mine = partial + (size_t)blockIdx.x * M * Q;
+    for (int i = threadIdx.x; i < M * Q; i += blockDim.x) mine[i] = 0.0;
+    const int64_t per = (U + gridDim.x - 1) / gridDim.x;
+    const int64_t k0 = blockIdx.x * per;
+    const int64_t k1 = k0 + per < U ? k0 + per : U;
+    double a1[SLOTS], a2[SLOTS], ap = 0.0;
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) a1[q] = a2[q] = 0.0;
+    int cur = -1;
+#define SRX_FLUSH(MM)                                        \
+    if ((MM) >= 0) {                                         \
+        double* dst = mine + (size_t)(MM) * Q;               \
+        _Pragma("unroll") for (int q = 0; q < SLOTS; ++q) {  \
+            const int p = threadIdx.x + q * blockDim.x;      \
+            if (p < SD) {                                    \
+                dst[S + p] += a1[q];                         \
+                dst[S + SD + p] += a2[q];                    \
+            }                                                \
+            a1[q] = a2[q] = 0.0;                             \
+        }                                                    \
+        if (threadIdx.x < S) dst[threadIdx.x] += ap;         \
+        ap = 0.0;                                            \
+    }
+    __syncthreads();
+    for (int64_t k = k0; k < k1; ++k) {
+        const int64_t u = utt_order ? utt_order[k] : k;
+        const int m = utt_model ? utt_model[u] : 0;
+        if (m != cur) {
+            SRX_FLUSH(cur);
+            cur = m;
+        }
+        const int64_t f0 = off[u], f1 = off[u + 1];
+        for (int64_t f = f0; f < f1; ++f) {
+            const T* g = gamma + f * S;
+            const T* x = X + f * D;
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q) {
+                const int p = threadIdx.x + q * blockDim.x;
+                if (p < SD) {
+                    const double gv = (double)g[p / D];
+                    const double xv = (double)x[p % D];
+                    a1[q] += gv * xv;
+                    a2[q] += gv * xv * xv;
+                }
+            }
+            if (threadIdx.x < S) ap += (double)g[threadIdx.x];
+        }
+    }
+    SRX_FLUSH(cur);
+#undef SRX_FLUSH
+}
+
+// Fixed-order sum of the per-workgroup partials into the packed records.
+__global__ void reduce_stats_kernel(const double* __restrict__ part_fb, int n_fb,
+                                    const double* __restrict__ part_obs, int n_obs, int M, int S,
+                                    int D, double* __restrict__ out) {
+    const srx_stats_layout L(S, D);
+    const int P = S * S + S + 2;
+    const int Q = S + 2 * S * D;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nth = gridDim.x * blockDim.x;
+    for (int i = tid; i < M * P; i += nth) {
+        const int m = i / P, r = i % P;
+        double s = 0.0;
+        for (int b = 0; b < n_fb; ++b) s += part_fb[(size_t)b * M * P + i];
+        int64_t dst;
+        if (r < S * S) dst = L.trans + r;
+        else if (r < S * S + S) dst = L.start + (r - S * S);
+        else if (r == S * S + S) dst = L.logprob;
+        else dst = L.nobs;
+        out[(size_t)m * L.size + dst] = s;
+    }
+    for (int i = tid; i < M * Q; i += nth) {
+        const int m = i / Q, r = i % Q;
+        double s = 0.0;
+        for (int b = 0; b < n_obs; ++b) s += part_obs[(size_t)b * M * Q + i];
+        const int64_t dst = r < S ? L.post + r : L.obs + (r - S);  // obs2 follows obs
+        out[(size_t)m * L.size + dst] = s;
+    }
+}
+
+template <typename T, int SP>
+__global__ void viterbi_chain_kernel(const T* __restrict__ loglik,
+                                     const int64_t* __restrict__ off, int64_t U,
+                                     const int32_t* __restrict__ utt_model, int S, Tables<T> tb,
+                                     uint8_t* __restrict__ bp, int32_t* __restrict__ path,
+                                     double* __restrict__ out_lp) {
+    const int j = threadIdx.x % SP;
+    const int64_t sub = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SP;
+    const int64_t nsub = (int64_t)gridDim.x * blockDim.x / SP;
+    for (int64_t u = sub; u < U; u += nsub) {
+        const int m = utt_model ? utt_model[u] : 0;
+        const int64_t f0 = off[u];
+        const int T_len = (int)(off[u + 1] - f0);
+        if (T_len <= 0) {
+            if (j == 0) out_lp[u] = 0.0;
+            continue;
+        }
+        T lacol[SP];
+#pragma unroll
+        for (int i = 0; i < SP; ++i)
+            lacol[i] = (i < S && j < S) ? tb.logA[((size_t)m * S + i) * S + j] : neg_inf<T>();
+        const T* ll = loglik + f0 * S + j;
+        uint8_t* b = bp + f0 * S + j;
+        T v = j < S ? tb.logpi[m * S + j] + ll[0] : neg_inf<T>();
+        for (int t = 1; t < T_len; ++t) {
+            T best = neg_inf<T>();
+            int arg = 0;
+#pragma unroll
+            for (int i = 0; i < SP; ++i) {
+                const T cand = __shfl(v, i, SP) + lacol[i];
+                if (cand > best) {   // strict: the lowest index wins ties (np.argmax)
+                    best = cand;
+                    arg = i;
+                }
+            }
+            if (j < S) {
+                v = best + ll[(int64_t)t * S];
+                b[(int64_t)t * S] = (uint8_t)arg;
+            }
+        }
+        T best = neg_inf<T>();
+        int arg = 0;
+#pragma unroll
+        for (int i = 0; i < SP; ++i) {
+            const T cand = __shfl(v, i, SP);
+            if (i < S && cand > best) {
+                best = cand;
+                arg = i;
+            }
+        }
+        if (j == 0) {
+            out_lp[u] = (double)best;
+            int s = arg;
+            path[f0 + T_len - 1] = s;
+            const uint8_t* bq = bp + f0 * S;
+            for (int t = T_len - 2; t >= 0; --t) {
+                s = bq[(int64_t)(t + 1) * S + s];
+                path[f0 + t] = s;
+            }
+        }
+    }
+}
+
+// One workgroup per model.
+__global__ void mstep_kernel(const double* __restrict__ stats, srx_priors_t pr, int mode,
+                             srx_models_t md) {
+    const int S = md.n_states, D = md.n_features, m = blockIdx.x;
+    const srx_stats_layout L(S, D);
+    const double* st = stats + (size_t)m * L.size;
+    double* pi = md.startprob + (size_t)m * S;
+    double* A = md.transmat + (size_t)m * S * S;
+    __shared__ double rowsum[65];
+    // start probabilities (hmm.py:445-448): structural zeros stay zero; the 1-D
+    // normalise divides by the plain sum.
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < S; ++i) {
+            double v = fmax(pr.startprob_prior - 1.0 + st[L.start + i], 0.0);
+            if (pi[i] == 0.0) v = 0.0;
+            pi[i] = v;
+            s += v;
+        }
+        rowsum[64] = s;
+    }
+    // transition rows (hmm.py:449-451): zero rows divide by 1.
+    if (threadIdx.x < S) {
+        const int i = threadIdx.x;
+        double s = 0.0;
+        for (int j = 0; j < S; ++j) {
+            double v = fmax(pr.transmat_prior - 1.0 + st[L.trans + i * S + j], 0.0);
+            if (A[i * S + j] == 0.0) v = 0.0;
+            A[i * S + j] = v;
+            s += v;
+        }
+        rowsum[i] = s == 0.0 ? 1.0 : s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < S; i += blockDim.x) pi[i] /= rowsum[64];
+    for (int i = threadIdx.x; i < S * S; i += blockDim.x) A[i] /= rowsum[i / S];
+    if (mode != SRX_MSTEP_FULL) return;
+    // means and diagonal covariances (hmm.py:168-184).
+    double* mu = md.means + (size_t)m * S * D;
+    double* cv = md.covars + (size_t)m * S * D;
+    for (int i = threadIdx.x; i < S * D; i += blockDim.x) {
+        const double denom = st[L.post + i / D];
+        const double obs = st[L.obs + i], obs2 = st[L.obs2 + i];
+        const double mean = (pr.means_weight * pr.means_prior + obs) / (pr.means_weight + denom);
+        const double diff = mean - pr.means_prior;
+        const double cn = pr.means_weight * diff * diff + obs2 - 2.0 * mean * obs +
+                          mean * mean * denom;
+        const double cd = fmax(pr.covars_weight - 1.0, 0.0) + denom;
+        mu[i] = mean;
+        cv[i] = (pr.covars_prior + cn) / fmax(cd, 1e-5);
+    }
+}
+
+int sub_width(int S) {
+    int sp = 2;
+    while (sp < S) sp <<= 1;
+    return sp;
+}
+
+template <typename T>
+int prepare(srx_context* h, const srx_models_t* md, Tables<T>* tb, hipStream_t st) {
+    void* base;
+    int rc = srx_ws_ensure(h, WS_PARAMS, tables_bytes<T>(md->n_models, md->n_states, md->n_features),
+                           &base);
+    if (rc) return rc;
+    *tb = carve_tables<T>(base, md->n_models, md->n_states, md->n_features);
+    hipLaunchKernelGGL(prep_kernel<T>, dim3(8), dim3(kBlock), 0, st, *md, (T*)tb->mu, (T*)tb->hinv,
+                       (T*)tb->cst, (T*)tb->A, (T*)tb->pi, (T*)tb->logA, (T*)tb->logpi);
+    SRX_HIP(hipGetLastError());
+    return SRX_OK;
+}
+
+int grid_for(srx_context* h, int64_t items, int per_block) {
+    int64_t g = (items + per_block - 1) / per_block;
+    const int64_t cap = (int64_t)h->n_cu * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+#define SP_DISPATCH(SPV, CALL)                     \
+    switch (SPV) {                                 \
+        case 2: { constexpr int SP = 2; CALL; } break;   \
+        case 4: { constexpr int SP = 4; CALL; } break;   \
+        case 8: { constexpr int SP = 8; CALL; } break;   \
+        case 16: { constexpr int SP = 16; CALL; } break; \
+        case 32: { constexpr int SP = 32; CALL; } break; \
+        default: { constexpr int SP = 64; CALL; } break; \
+    }
+
+template <typename T>
+int emission_t(srx_context* h, const void* X, int64_t n_frames, const srx_models_t* md, void* out,
+               hipStream_t st) {
+    Tables<T> tb;
+    int rc = prepare<T>(h, md, &tb, st);
+    if (rc) return rc;
+    // A single pseudo-utterance spanning all frames would serialise on one
+    // workgroup; cut the frame range into fixed slices instead.
+    const int64_t slice = 256;
+    const int64_t n_slices = (n_frames + slice - 1) / slice;
+    int64_t* offs;
+    rc = srx_ws_ensure(h, WS_MISC, sizeof(int64_t) * (n_slices + 1), (void**)&offs);
+    if (rc) return rc;
+    hipLaunchKernelGGL(srx_fill_slices, dim3(grid_for(h, n_slices + 1, kBlock)), dim3(kBlock), 0, st,
+                       offs, n_slices, slice, n_frames);
+    hipLaunchKernelGGL(emission_kernel<T>, dim3(grid_for(h, n_slices, 1)), dim3(kBlock), 0, st,
+                       (const T*)X, (const int64_t*)offs, n_slices, (const int32_t*)nullptr, 1,
+                       md->n_models, md->n_states, md->n_features, tb, (T*)out);
+    SRX_HIP(hipGetLastError());
+    return SRX_OK;
+}
+
+template <typename T>
+int score_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
+            const srx_models_t* md, double* out, hipStream_t st) {
+    const int M = md->n_models, S = md->n_states, D = md->n_features;
+    Tables<T> tb;
+    int rc = prepare<T>(h, md, &tb, st);
+    if (rc) return rc;
+    T* ll;
+    rc = srx_ws_ensure(h, WS_LOGLIK, sizeof(T) * (size_t)n_frames * M * S, (void**)&ll);
+    if (rc) return rc;
+    hipLaunchKernelGGL(emission_kernel<T>, dim3(grid_for(h, U, 1)), dim3(kBlock), 0, st,
+                       (const T*)X, off, U, (const int32_t*)nullptr, 1, M, S, D, tb, ll);
+    const int sp = sub_width(S);
+    SP_DISPATCH(sp, hipLaunchKernelGGL((score_chain_kernel<T, SP>),
+                                       dim3(grid_for(h, U * M, kBlock / SP)), dim3(kBlock), 0, st,
+                                       (const T*)ll, off, U, M, S, tb, out));
+    SRX_HIP(hipGetLastError());
+    return SRX_OK;
+}
+
+template <typename T>
+int viterbi_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
+              const int32_t* utt_model, const srx_models_t* md, int32_t* path, double* lp,
+              hipStream_t st) {
+    const int M = md->n_models, S = md->n_states, D = md->n_features;
+    Tables<T> tb;
+    int rc = prepare<T>(h, md, &tb, st);
+    if (rc) return rc;
+    T* ll;
+    uint8_t* bp;
+    rc = srx_ws_ensure(h, WS_LOGLIK, sizeof(T) * (size_t)n_frames * S, (void**)&ll);
+    if (rc) return rc;
+    rc = srx_ws_ensure(h, WS_BACKPTR, (size_t)n_frames * S, (void**)&bp);
+    if (rc) return rc;
+    hipLaunchKernelGGL(emission_kernel<T>, dim3(grid_for(h, U, 1)), dim3(kBlock), 0, st,
+                       (const T*)X, off, U, utt_model, 0, M, S, D, tb, ll);
+    const int sp = sub_width(S);
+    SP_DISPATCH(sp, hipLaunchKernelGGL((viterbi_chain_kernel<T, SP>),
+                                       dim3(grid_for(h, U, kBlock / SP)), dim3(kBlock), 0, st,
+                                       (const T*)ll, off, U, utt_model, S, tb, bp, path, lp));
+    SRX_HIP(hipGetLastError());
+    return SRX_OK;
+}
+
+template <typename T>
+int estep_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
+            const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* md,
+            double* out_stats, hipStream_t st) {
+    const int M = md->n_models, S = md->n_states, D = md->n_features;
+    Tables<T> tb;
+    int rc = prepare<T>(h, md, &tb, st);
+    if (rc) return rc;
+    T *ll, *lat, *sc;
+    rc = srx_ws_ensure(h, WS_LOGLIK, sizeof(T) * (size_t)n_frames * S, (void**)&ll);
+    if (rc) return rc;
+    rc = srx_ws_ensure(h, WS_LATTICE, sizeof(T) * (size_t)n_frames * S, (void**)&lat);
+    if (rc) return rc;
+    rc = srx_ws_ensure(h, WS_SCALE, sizeof(T) * (size_t)n_frames, (void**)&sc);
+    if (rc) return rc;
+    const int sp = sub_width(S);
+    const int P = S * S + S + 2, Q = S + 2 * S * D;
+    const int g_fb = grid_for(h, U, kBlock / sp);
+    int g_obs = grid_for(h, U, 4);
+    if (g_obs > 1024) g_obs = 1024;
+    double* part;
+    rc = srx_ws_ensure(h, WS_PARTIAL, sizeof(double) * ((size_t)g_fb * M * P + (size_t)g_obs * M * Q),
+                       (void**)&part);
+    if (rc) return rc;
+    double* part_obs = part + (size_t)g_fb * M * P;
+    const size_t lds = sizeof(double) * (size_t)M * P;
+    SRX_REQUIRE(lds <= 64 * 1024, "estep: %d models x %d states need %zu bytes of LDS (max 65536)",
+                M, S, lds);
+    hipLaunchKernelGGL(emission_kernel<T>, dim3(grid_for(h, U, 1)), dim3(kBlock), 0, st,
+                       (const T*)X, off, U, utt_model, 0, M, S, D, tb, ll);
+    SP_DISPATCH(sp, hipLaunchKernelGGL((fb_chain_kernel<T, SP>), dim3(g_fb), dim3(kBlock), lds, st,
+                                       (const T*)ll, off, U, utt_model, utt_order, M, S, tb, lat,
+                                       sc, part));
+    const int slots = (S * D + kBlock - 1) / kBlock;
+    SRX_REQUIRE(slots <= 16, "estep: n_states*n_features = %d exceeds %d", S * D, 16 * kBlock);
+#define OBS(SL)                                                                                   \
+    hipLaunchKernelGGL((obs_stats_kernel<T, SL>), dim3(g_obs), dim3(kBlock), 0, st, (const T*)X,  \
+                       (const T*)lat, off, U, utt_model, utt_order, M, S, D, part_obs)
+    if (slots <= 1) OBS(1);
+    else if (slots <= 2) OBS(2);
+    else if (slots <= 4) OBS(4);
+    else if (slots <= 8) OBS(8);
+    else OBS(16);
+#undef OBS
+    hipLaunchKernelGGL(reduce_stats_kernel, dim3(8), dim3(kBlock), 0, st, (const double*)part, g_fb,
+                       (const double*)part_obs, g_obs, M, S, D, out_stats);
+    SRX_HIP(hipGetLastError());
+    return SRX_OK;
+}
+
+}  // namespace
+
+__global__ void srx_fill_slices(int64_t* offs, int64_t n_slices, int64_t slice, int64_t n_frames) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = i; k <= n_slices; k += step) {
+        const int64_t v = k * slice;
+        offs[k] = v < n_frames ? v : n_frames;
+    }
+}
+
+int srx_generic_emission(srx_context* h, const void* X, int dtype, int64_t n_frames,
+                         const srx_models_t* md, void* out, hipStream_t st) {
+    return dtype == SRX_F64 ? emission_t<double>(h, X, n_frames, md, out, st)
+                            : emission_t<float>(h, X, n_frames, md, out, st);
+}
+
+int srx_generic_score(srx_context* h, const void* X, int dtype, const int64_t* off, int64_t U,
+                      int64_t n_frames, const srx_models_t* md, double* out, hipStream_t st) {
+    return dtype == SRX_F64 ? score_t<double>(h, X, off, U, n_frames, md, out, st)
+                            : score_t<float>(h, X, off, U, n_frames, md, out, st);
+}
+
+int srx_generic_viterbi(srx_context* h, const void* X, int dtype, const int64_t* off, int64_t U,
+                        int64_t n_frames, const int32_t* utt_model, const srx_models_t* md,
+                        int32_t* path, double* lp, hipStream_t st) {
+    return dtype == SRX_F64 ? viterbi_t<double>(h, X, off, U, n_frames, utt_model, md, path, lp, st)
+                            : viterbi_t<float>(h, X, off, U, n_frames, utt_model, md, path, lp, st);
+}
+
+int srx_generic_estep(srx_context* h, const void* X, int dtype, const int64_t* off, int64_t U,
+                      int64_t n_frames, const int32_t* utt_model, const int64_t* utt_order,
+                      const srx_models_t* md, double* out_stats, hipStream_t st) {
+    return dtype == SRX_F64
+               ? estep_t<double>(h, X, off, U, n_frames, utt_model, utt_order, md, out_stats, st)
+               : estep_t<float>(h, X, off, U, n_frames, utt_model, utt_order, md, out_stats, st);
+}
+
+int srx_generic_mstep(srx_context* h, const double* stats, const srx_priors_t* pr, int mode,
+                      const srx_models_t* md, hipStream_t st) {
+    SRX_REQUIRE(md->n_states <= 64, "mstep: n_states %d > 64", md->n_states);
+    hipLaunchKernelGGL(mstep_kernel, dim3(md->n_models), dim3(kBlock), 0, st, stats, *pr, mode, *md);
+    SRX_HIP(hipGetLastError());
+    return SRX_OK;
+}

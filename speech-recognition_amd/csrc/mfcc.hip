@@ -1,0 +1,440 @@
+// MFCC front-end: frames -> Hamming -> real FFT -> |.|^2/N -> mel triangles ->
+// log10 -> DCT-II -> regression deltas -> per-utterance z-score.
+//
+// Two kernels over ragged, packed utterances:
+//   cepstra_kernel  one wave per frame.  The frame is read once from HBM
+//                   (coalesced), windowed, packed as N/2 complex points and
+//                   transformed in LDS (radix-2, bit-reversed load), unpacked to
+//                   the N/2+1 real-input bins, reduced through the sparse mel
+//                   triangles (every bin feeds at most two filters) and the
+//                   DCT rows kept in L1/L2.  Work items are cut from the packed
+//                   SAMPLE axis, so a few long recordings and many short ones
+//                   load the chip equally.
+//   finish_kernel   one workgroup per utterance: deltas with edge clamping,
+//                   trim of delta_n frames at both ends, z-score (two-pass).
+#include "srx_internal.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kChunkFrames = 16;  // frames per work item of cepstra_kernel
+
+template <typename T> struct cplx { T re, im; };
+
+// Lanes of one wave exchange data through LDS: the hardware executes a wave's
+// LDS instructions in order, so only the compiler has to be kept from moving
+// accesses across the hand-over points.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T> __device__ __forceinline__ T eps_of();
+template <> __device__ __forceinline__ float eps_of<float>() { return 1.1920929e-07f; }
+template <> __device__ __forceinline__ double eps_of<double>() { return 2.220446049250313e-16; }
+
+struct MfccDev {
+    int frame_len, hop, nfft, log2h, n_mel, n_ceps;   // log2h = log2(nfft/2)
+    int n_used;                                        // min(frame_len, nfft)
+    const int32_t* mel_ptr;
+    const int32_t* mel_bin;
+    double log_mult;
+};
+
+__device__ __forceinline__ int64_t raw_frames(int64_t n, int L, int hop) {
+    return n < L ? 0 : (n - L) / hop + 1;
+}
+
+template <typename T>
+__global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __restrict__ so,
+                               int64_t U, int64_t total, MfccDev c, const T* __restrict__ window,
+                               const cplx<T>* __restrict__ tw, const T* __restrict__ mel_w,
+                               const T* __restrict__ dct, T* __restrict__ cep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int H = c.nfft >> 1;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int n_waves = blockDim.x / kWave;
+    // per-wave LDS: H complex, H+1 power bins, n_mel log energies
+    const size_t per_wave = sizeof(T) * ((size_t)2 * H + (H + 1) + c.n_mel + 1);
+    cplx<T>* z = (cplx<T>*)(smem_raw + per_wave * wave);
+    T* pw = (T*)(z + H);
+    T* lm = pw + (H + 1);
+
+    const int64_t chunk = (int64_t)kChunkFrames * c.hop;
+    const int64_t n_chunks = (total + chunk - 1) / chunk;
+    for (int64_t b = blockIdx.x; b < n_chunks; b += gridDim.x) {
+        const int64_t p0 = b * chunk;
+        const int64_t p1 = p0 + chunk < total ? p0 + chunk : total;
+        // last utterance whose first sample is <= p0
+        int64_t lo = 0, hi = U;
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (so[mid] <= p0) lo = mid; else hi = mid;
+        }
+        int item = 0;
+        for (int64_t u = lo; u < U && so[u] < p1; ++u) {
+            const int64_t s0 = so[u], n = so[u + 1] - s0;
+            const int64_t Tu = raw_frames(n, c.frame_len, c.hop);
+            const int64_t a = p0 > s0 ? p0 - s0 : 0;
+            int64_t ta = (a + c.hop - 1) / c.hop;
+            int64_t tb = (p1 - s0 + c.hop - 1) / c.hop;
+            if (tb > Tu) tb = Tu;
+            const int64_t row0 = s0 / c.hop;   // first cepstra row of this utterance
+            for (int64_t t = ta; t < tb; ++t, ++item) {
+                if (item % n_waves != wave) continue;
+                const T* x = audio + s0 + t * c.hop;
+                // ---- load, window, pack even/odd samples, bit-reversed store
+                for (int k = lane; k < H; k += kWave) {
+                    const int n0 = 2 * k, n1 = 2 * k + 1;
+                    cplx<T> v;
+                    v.re = n0 < c.n_used ? x[n0] * window[n0] : (T)0;
+                    v.im = n1 < c.n_used ? x[n1] * window[n1] : (T)0;
+                    const int r = (int)(__brev((unsigned)k) >> (32 - c.log2h));
+                    z[r] = v;
+                }
+                wave_sync();
+                // ---- radix-2 DIT, H points; tw[k] = exp(-2 pi i k / nfft)
+                for (int s = 0; s < c.log2h; ++s) {
+                    const int half = 1 << s;
+                    const int tstep = c.nfft >> (s + 1);   // W_H^(pos*H/(2 half)) = W_N^(pos*N/(2 half))
+                    for (int q = lane; q < (H >> 1); q += kWave) {
+                        const int pos = q & (half - 1);
+                        const int i = ((q >> s) << (s + 1)) + pos;
+                        const int j = i + half;
+                        const cplx<T> w = tw[pos * tstep];
+                        const cplx<T> zi = z[i], zj = z[j];
+                        const T tr = w.re * zj.re - w.im * zj.im;
+                        const T ti = w.re * zj.im + w.im * zj.re;
+                        z[i].re = zi.re + tr; z[i].im = zi.im + ti;
+                        z[j].re = zi.re - tr; z[j].im = zi.im - ti;
+                    }
+                    wave_sync();
+                }
+                // ---- unpack to the real-input spectrum, power / nfft
+                const T inv_n = (T)1 / (T)c.nfft;
+                for (int k = lane; k <= H; k += kWave) {
+                    const cplx<T> zk = z[k & (H - 1)];
+                    const cplx<T> zc = z[(H - k) & (H - 1)];
+                    const T er = (T)0.5 * (zk.re + zc.re), ei = (T)0.5 * (zk.im - zc.im);
+                    const T orr = (T)0.5 * (zk.im + zc.im), oi = (T)-0.5 * (zk.re - zc.re);
+                    const cplx<T> w = tw[k];
+                    const T xr = er + w.re * orr - w.im * oi;
+                    const T xi = ei + w.re * oi + w.im * orr;
+                    pw[k] = (xr * xr + xi * xi) * inv_n;
+                }
+                wave_sync();
+                // ---- mel triangles (CSR), exact zeros -> eps, log_mult * log10
+                for (int m = lane; m < c.n_mel; m += kWave) {
+                    T e = 0;
+                    for (int q = c.mel_ptr[m]; q < c.mel_ptr[m + 1]; ++q) e += pw[c.mel_bin[q]] * mel_w[q];
+                    if (e == (T)0) e = (T)2.220446049250313e-16;   // np.finfo(float).eps, mfcc.py:43
+                    lm[m] = (T)c.log_mult * log10(e);
+                }
+                wave_sync();
+                // ---- DCT-II rows
+                T* dst = cep + (row0 + t) * c.n_ceps;
+                for (int k = lane; k < c.n_ceps; k += kWave) {
+                    T acc = 0;
+                    const T* row = dct + (size_t)k * c.n_mel;
+                    for (int m = 0; m < c.n_mel; ++m) acc += row[m] * lm[m];
+                    dst[k] = acc;
+                }
+                wave_sync();
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int64_t clamp_t(int64_t t, int64_t Tu) {
+    return t < 0 ? 0 : (t >= Tu ? Tu - 1 : t);
+}
+
+// Feature block `ord` (0 = cepstrum, 1 = delta, 2 = delta of the untrimmed
+// delta) at raw frame t, coefficient k; edge frames are repeated (np.pad
+// mode='edge', mfcc.py:93).
+template <typename T>
+__device__ __forceinline__ T delta_at(const T* __restrict__ cep, int K, int64_t Tu, int64_t t, int k,
+                                      int ord, int N, T inv_den) {
+    if (ord == 0) return cep[t * K + k];
+    if (ord == 1) {
+        T acc = 0;
+        for (int j = -N; j <= N; ++j) acc += (T)j * cep[clamp_t(t + j, Tu) * K + k];
+        return acc * inv_den;
+    }
+    T acc2 = 0;
+    for (int i = -N; i <= N; ++i) {
+        const int64_t ti = clamp_t(t + i, Tu);
+        T acc = 0;
+        for (int j = -N; j <= N; ++j) acc += (T)j * cep[clamp_t(ti + j, Tu) * K + k];
+        acc2 += (T)i * (acc * inv_den);
+    }
+    return acc2 * inv_den;
+}
+
+template <typename T>
+__global__ void finish_kernel(const T* __restrict__ cep, const int64_t* __restrict__ so,
+                              const int64_t* __restrict__ fo, int64_t U, MfccDev c, int order,
+                              int N, int zscore, T* __restrict__ out) {
+    __shared__ double red[256];
+    __shared__ T col_mean[128], col_scale[128];
+    const int K = c.n_ceps, NF = K * (1 + order);
+    int den = 0;
+    for (int i = 1; i <= N; ++i) den += 2 * i * i;
+    const T inv_den = (T)1 / (T)den;
+    for (int64_t u = blockIdx.x; u < U; u += gridDim.x) {
+        const int64_t s0 = so[u], n = so[u + 1] - s0;
+        const int64_t Tu = raw_frames(n, c.frame_len, c.hop);
+        const int trim = order > 0 ? N : 0;
+        const int64_t To = Tu - 2 * trim > 0 ? Tu - 2 * trim : 0;
+        const T* cu = cep + (s0 / c.hop) * K;
+        T* ou = out + fo[u] * NF;
+        for (int64_t idx = threadIdx.x; idx < To * NF; idx += blockDim.x) {
+            const int64_t t = idx / NF;
+            const int f = (int)(idx % NF);
+            ou[idx] = delta_at<T>(cu, K, Tu, t + trim, f % K, f / K, N, inv_den);
+        }
+        if (!zscore || To == 0) continue;
+        __syncthreads();
+        // column sums: thread -> (column f, row group r)
+        const int groups = blockDim.x / NF;
+        const int f = threadIdx.x % NF, r = threadIdx.x / NF;
+        const bool active = r < groups;
+        for (int pass = 0; pass < 2; ++pass) {
+            double acc = 0.0;
+            if (active)
+                for (int64_t t = r; t < To; t += groups) {
+                    const double v = (double)ou[t * NF + f];
+                    if (pass == 0) acc += v;
+                    else { const double d = v - (double)col_mean[f]; acc += d * d; }
+                }
+            red[threadIdx.x] = acc;
+            __syncthreads();
+            if (threadIdx.x < NF) {
+                double s = 0.0;
+                for (int g = 0; g < groups; ++g) s += red[g * NF + threadIdx.x];
+                if (pass == 0) {
+                    col_mean[threadIdx.x] = (T)(s / (double)To);
+                } else {
+                    const T var = (T)(s / (double)To);
+                    const T mean = col_mean[threadIdx.x];
+                    const T e = eps_of<T>();
+                    const T bound = (T)To * e * var + ((T)To * mean * e) * ((T)To * mean * e);
+                    T sc = sqrt(var);
+                    if (var <= bound || sc == (T)0) sc = (T)1;   // constant column keeps scale 1
+                    col_scale[threadIdx.x] = sc;
+                }
+            }
+            __syncthreads();
+        }
+        for (int64_t idx = threadIdx.x; idx < To * NF; idx += blockDim.x) {
+            const int ff = (int)(idx % NF);
+            ou[idx] = (ou[idx] - col_mean[ff]) / col_scale[ff];
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+int upload(const std::vector<double>& v, void** dst) {
+    std::vector<T> tmp(v.begin(), v.end());
+    SRX_HIP(hipMalloc(dst, sizeof(T) * (tmp.size() ? tmp.size() : 1)));
+    SRX_HIP(hipMemcpy(*dst, tmp.data(), sizeof(T) * tmp.size(), hipMemcpyHostToDevice));
+    return SRX_OK;
+}
+
+// Host-side dense filterbank exactly as the reference builds it (mfcc.py:47-61).
+void build_filterbank(const srx_mfcc_cfg_t& c, std::vector<double>& fb, int& nbins) {
+    nbins = c.nfft / 2 + 1;
+    fb.assign((size_t)c.n_mel * nbins, 0.0);
+    const double top = 2595.0 * log10(1.0 + (double)c.mel_sample_rate / 2 / 700);
+    std::vector<double> edge(c.n_mel + 2);
+    const double step = top / (c.n_mel + 1);
+    for (int i = 0; i < c.n_mel + 2; ++i) {
+        const double mel = i == c.n_mel + 1 ? top : i * step;
+        const double hz = 700 * (pow(10.0, mel / 2595) - 1);
+        edge[i] = floor((c.nfft + 1) * hz / c.mel_sample_rate);
+    }
+    for (int m = 0; m < c.n_mel; ++m) {
+        const double lo = edge[m], mid = edge[m + 1], hi = edge[m + 2];
+        for (int k = (int)lo; k < (int)mid && k < nbins; ++k) fb[(size_t)m * nbins + k] = (k - lo) / (mid - lo);
+        for (int k = (int)mid; k < (int)hi && k < nbins; ++k) fb[(size_t)m * nbins + k] = (hi - k) / (hi - mid);
+    }
+}
+
+int check_cfg(const srx_mfcc_cfg_t* c) {
+    SRX_REQUIRE(c != nullptr, "mfcc: NULL cfg");
+    SRX_REQUIRE(c->nfft >= 64 && c->nfft <= 4096 && (c->nfft & (c->nfft - 1)) == 0,
+                "mfcc: nfft %d must be a power of two in [64, 4096]", c->nfft);
+    SRX_REQUIRE(c->frame_len >= 1 && c->hop >= 1 && c->hop <= c->frame_len,
+                "mfcc: need 1 <= hop (%d) <= frame_len (%d)", c->hop, c->frame_len);
+    SRX_REQUIRE(c->n_mel >= 1 && c->n_mel <= 128, "mfcc: n_mel %d outside [1, 128]", c->n_mel);
+    SRX_REQUIRE(c->n_ceps >= 1 && c->n_ceps <= c->n_mel && c->n_ceps <= 32,
+                "mfcc: n_ceps %d outside [1, min(n_mel, 32)]", c->n_ceps);
+    SRX_REQUIRE(c->delta_order >= 0 && c->delta_order <= 2, "mfcc: delta_order %d outside [0, 2]",
+                c->delta_order);
+    SRX_REQUIRE(c->delta_n >= 1 && c->delta_n <= 8, "mfcc: delta_n %d outside [1, 8]", c->delta_n);
+    SRX_REQUIRE(c->mel_sample_rate > 0 && c->sample_rate > 0, "mfcc: sample rates must be positive");
+    return SRX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t srx_mfcc_out_frames(const srx_mfcc_cfg_t* c, int64_t n_samples) {
+    if (!c || n_samples < c->frame_len) return 0;
+    const int64_t t = (n_samples - c->frame_len) / c->hop + 1;
+    if (c->delta_order == 0) return t;
+    return t > 2 * c->delta_n ? t - 2 * c->delta_n : 0;
+}
+
+int srx_mfcc_plan_create(srx_handle_t h, const srx_mfcc_cfg_t* cfg, srx_mfcc_plan_t* out) {
+    SRX_REQUIRE(h != nullptr && out != nullptr, "srx_mfcc_plan_create: NULL argument");
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    SRX_HIP(hipSetDevice(h->device));
+    srx_mfcc_plan* p = new srx_mfcc_plan();
+    memset(p, 0, sizeof(*p));
+    p->ctx = h;
+    p->cfg = *cfg;
+    int l2 = 0;
+    while ((1 << l2) < cfg->nfft) ++l2;
+    p->log2n = l2;
+    const int N = cfg->nfft, H = N / 2;
+    const int used = cfg->frame_len < N ? cfg->frame_len : N;   // rfft(frames, NFFT) crops
+    std::vector<double> win(cfg->frame_len), tw(2 * (size_t)(H + 1));
+    for (int i = 0; i < cfg->frame_len; ++i)
+        win[i] = cfg->frame_len == 1 ? 1.0
+                                     : 0.54 - 0.46 * cos(2.0 * M_PI * i / (cfg->frame_len - 1));
+    (void)used;
+    for (int k = 0; k <= H; ++k) {
+        tw[2 * k] = cos(2.0 * M_PI * k / N);
+        tw[2 * k + 1] = -sin(2.0 * M_PI * k / N);
+    }
+    std::vector<double> fb;
+    int nbins;
+    build_filterbank(*cfg, fb, nbins);
+    std::vector<double> w;
+    std::vector<int32_t> bins, ptr(cfg->n_mel + 1, 0);
+    for (int m = 0; m < cfg->n_mel; ++m) {
+        for (int k = 0; k < nbins; ++k)
+            if (fb[(size_t)m * nbins + k] != 0.0) {
+                w.push_back(fb[(size_t)m * nbins + k]);
+                bins.push_back(k);
+            }
+        ptr[m + 1] = (int32_t)w.size();
+    }
+    p->nnz = (int)w.size();
+    std::vector<double> dct((size_t)cfg->n_ceps * cfg->n_mel);
+    for (int k = 0; k < cfg->n_ceps; ++k)
+        for (int n = 0; n < cfg->n_mel; ++n) {
+            double v = sqrt(2.0 / cfg->n_mel) * cos(M_PI * k * (2 * n + 1) / (2.0 * cfg->n_mel));
+            if (k == 0) v *= 1.0 / sqrt(2.0);
+            dct[(size_t)k * cfg->n_mel + n] = v;
+        }
+    rc = upload<float>(win, &p->window[0]);   if (rc) return rc;
+    rc = upload<double>(win, &p->window[1]);  if (rc) return rc;
+    rc = upload<float>(tw, &p->twiddle[0]);   if (rc) return rc;
+    rc = upload<double>(tw, &p->twiddle[1]);  if (rc) return rc;
+    rc = upload<float>(w, &p->mel_w[0]);      if (rc) return rc;
+    rc = upload<double>(w, &p->mel_w[1]);     if (rc) return rc;
+    rc = upload<float>(dct, &p->dct[0]);      if (rc) return rc;
+    rc = upload<double>(dct, &p->dct[1]);     if (rc) return rc;
+    SRX_HIP(hipMalloc((void**)&p->mel_bin, sizeof(int32_t) * (bins.size() ? bins.size() : 1)));
+    SRX_HIP(hipMemcpy(p->mel_bin, bins.data(), sizeof(int32_t) * bins.size(), hipMemcpyHostToDevice));
+    SRX_HIP(hipMalloc((void**)&p->mel_ptr, sizeof(int32_t) * ptr.size()));
+    SRX_HIP(hipMemcpy(p->mel_ptr, ptr.data(), sizeof(int32_t) * ptr.size(), hipMemcpyHostToDevice));
+    *out = p;
+    return SRX_OK;
+}
+
+int srx_mfcc_plan_destroy(srx_mfcc_plan_t p) {
+    if (!p) return SRX_OK;
+    (void)hipSetDevice(p->ctx->device);
+    for (int i = 0; i < 2; ++i) {
+        (void)hipFree(p->window[i]);
+        (void)hipFree(p->twiddle[i]);
+        (void)hipFree(p->mel_w[i]);
+        (void)hipFree(p->dct[i]);
+    }
+    (void)hipFree(p->mel_bin);
+    (void)hipFree(p->mel_ptr);
+    delete p;
+    return SRX_OK;
+}
+
+int srx_mfcc_filterbank_host(const srx_mfcc_cfg_t* cfg, double* out_dense) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    SRX_REQUIRE(out_dense != nullptr, "srx_mfcc_filterbank_host: NULL out");
+    std::vector<double> fb;
+    int nbins;
+    build_filterbank(*cfg, fb, nbins);
+    memcpy(out_dense, fb.data(), sizeof(double) * fb.size());
+    return SRX_OK;
+}
+
+int srx_mfcc_batch(srx_handle_t h, srx_mfcc_plan_t p, const void* audio, int dtype,
+                   const int64_t* sample_offsets, int64_t n_utts, int64_t n_samples,
+                   void* out_feats, const int64_t* frame_offsets, void* stream) {
+    SRX_REQUIRE(h != nullptr && p != nullptr, "srx_mfcc_batch: NULL context or plan");
+    SRX_REQUIRE(p->ctx == h, "srx_mfcc_batch: plan belongs to another context");
+    SRX_REQUIRE(dtype == SRX_F32 || dtype == SRX_F64, "srx_mfcc_batch: unknown dtype %d", dtype);
+    SRX_REQUIRE(n_utts >= 0 && n_samples >= 0, "srx_mfcc_batch: negative size");
+    if (n_utts == 0 || n_samples == 0) return SRX_OK;
+    SRX_REQUIRE(audio && sample_offsets && frame_offsets && out_feats,
+                "srx_mfcc_batch: NULL buffer");
+    SRX_HIP(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const srx_mfcc_cfg_t& c = p->cfg;
+    const int H = c.nfft / 2;
+    MfccDev d;
+    d.frame_len = c.frame_len; d.hop = c.hop; d.nfft = c.nfft; d.log2h = p->log2n - 1;
+    d.n_mel = c.n_mel; d.n_ceps = c.n_ceps;
+    d.n_used = c.frame_len < c.nfft ? c.frame_len : c.nfft;
+    d.mel_ptr = p->mel_ptr; d.mel_bin = p->mel_bin; d.log_mult = c.log_mult;
+    const size_t esz = dtype == SRX_F64 ? 8 : 4;
+    const int64_t rows = n_samples / c.hop + 1;
+    void* cep;
+    int rc = srx_ws_ensure(h, WS_CEPSTRA, esz * (size_t)rows * c.n_ceps, &cep);
+    if (rc) return rc;
+    const size_t per_wave = esz * ((size_t)2 * H + (H + 1) + c.n_mel + 1);
+    int waves = 4;
+    while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
+    SRX_REQUIRE(per_wave * waves <= 64 * 1024, "srx_mfcc_batch: nfft %d needs %zu bytes of LDS",
+                c.nfft, per_wave);
+    const int64_t chunk = (int64_t)kChunkFrames * c.hop;
+    int64_t n_chunks = (n_samples + chunk - 1) / chunk;
+    int64_t grid = n_chunks < (int64_t)h->n_cu * 16 ? n_chunks : (int64_t)h->n_cu * 16;
+    int64_t grid2 = n_utts < (int64_t)h->n_cu * 8 ? n_utts : (int64_t)h->n_cu * 8;
+    const int idx = dtype == SRX_F64 ? 1 : 0;
+    if (dtype == SRX_F64) {
+        hipLaunchKernelGGL(cepstra_kernel<double>, dim3((unsigned)grid), dim3(waves * kWave),
+                           per_wave * waves, st, (const double*)audio, sample_offsets, n_utts,
+                           n_samples, d, (const double*)p->window[idx],
+                           (const cplx<double>*)p->twiddle[idx], (const double*)p->mel_w[idx],
+                           (const double*)p->dct[idx], (double*)cep);
+        hipLaunchKernelGGL(finish_kernel<double>, dim3((unsigned)grid2), dim3(256), 0, st,
+                           (const double*)cep, sample_offsets, frame_offsets, n_utts, d,
+                           c.delta_order, c.delta_n, c.zscore, (double*)out_feats);
+    } else {
+        hipLaunchKernelGGL(cepstra_kernel<float>, dim3((unsigned)grid), dim3(waves * kWave),
+                           per_wave * waves, st, (const float*)audio, sample_offsets, n_utts,
+                           n_samples, d, (const float*)p->window[idx],
+                           (const cplx<float>*)p->twiddle[idx], (const float*)p->mel_w[idx],
+                           (const float*)p->dct[idx], (float*)cep);
+        hipLaunchKernelGGL(finish_kernel<float>, dim3((unsigned)grid2), dim3(256), 0, st,
+                           (const float*)cep, sample_offsets, frame_offsets, n_utts, d,
+                           c.delta_order, c.delta_n, c.zscore, (float*)out_feats);
+    }
+    SRX_HIP(hipGetLastError());
+    return SRX_OK;
+}
+
+}  // extern "C"

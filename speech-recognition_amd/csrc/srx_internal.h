@@ -1,0 +1,101 @@
+// Internal declarations shared by the libsrx translation units (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "srx.h"
+
+// Scratch buffers owned by a context; grown on demand, never shrunk.
+enum srx_ws_slot {
+    WS_PARAMS = 0,   // prepared model tables in the compute dtype
+    WS_LOGLIK,       // [n_frames, n_cols] emission log-densities
+    WS_LATTICE,      // [n_frames, S] scaled forward lattice, then posteriors
+    WS_SCALE,        // [n_frames] per-frame scaling constants
+    WS_PARTIAL,      // per-workgroup partial statistics
+    WS_BACKPTR,      // [n_frames, S] Viterbi back-pointers (uint8)
+    WS_CEPSTRA,      // [raw frames, n_ceps] cepstra before the delta stage
+    WS_MISC,
+    WS_NUM
+};
+
+struct srx_context {
+    int device;
+    int n_cu;
+    void* ws[WS_NUM];
+    size_t ws_bytes[WS_NUM];
+};
+
+struct srx_mfcc_plan {
+    srx_context* ctx;
+    srx_mfcc_cfg_t cfg;
+    int log2n;             // log2(nfft)
+    // device tables (both precisions are kept so either dtype can run)
+    void* window[2];       // [frame_len]
+    void* twiddle[2];      // [nfft/2] complex (cos, -sin)
+    void* mel_w[2];        // [nnz] filter weights, filter-major
+    int32_t* mel_bin;      // [nnz] spectrum bin of each weight
+    int32_t* mel_ptr;      // [n_mel+1] CSR row pointers
+    void* dct[2];          // [n_ceps, n_mel]
+    int nnz;
+};
+
+void srx_set_error(const char* fmt, ...);
+int srx_ws_ensure(srx_context* h, int slot, size_t bytes, void** out);
+
+#define SRX_HIP(call)                                                            \
+    do {                                                                         \
+        hipError_t e__ = (call);                                                 \
+        if (e__ != hipSuccess) {                                                 \
+            srx_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                          __FILE__, __LINE__);                                   \
+            return SRX_EHIP;                                                     \
+        }                                                                        \
+    } while (0)
+
+#define SRX_REQUIRE(cond, ...)           \
+    do {                                 \
+        if (!(cond)) {                   \
+            srx_set_error(__VA_ARGS__);  \
+            return SRX_EINVAL;           \
+        }                                \
+    } while (0)
+
+// Layout of one packed statistics record (doubles).
+struct srx_stats_layout {
+    int64_t nobs, logprob, start, trans, post, obs, obs2, size;
+    __host__ __device__ srx_stats_layout(int S, int D) {
+        nobs = 0;
+        logprob = 1;
+        start = 2;
+        trans = start + S;
+        post = trans + (int64_t)S * S;
+        obs = post + S;
+        obs2 = obs + (int64_t)S * D;
+        size = obs2 + (int64_t)S * D;
+    }
+};
+
+// Implemented in hmm_generic.hip
+int srx_generic_emission(srx_context* h, const void* X, int dtype, int64_t n_frames,
+                         const srx_models_t* models, void* out, hipStream_t st);
+int srx_generic_score(srx_context* h, const void* X, int dtype, const int64_t* off,
+                      int64_t U, int64_t n_frames, const srx_models_t* models,
+                      double* out, hipStream_t st);
+int srx_generic_viterbi(srx_context* h, const void* X, int dtype, const int64_t* off,
+                        int64_t U, int64_t n_frames, const int32_t* utt_model,
+                        const srx_models_t* models, int32_t* path, double* logprob,
+                        hipStream_t st);
+int srx_generic_estep(srx_context* h, const void* X, int dtype, const int64_t* off,
+                      int64_t U, int64_t n_frames, const int32_t* utt_model,
+                      const int64_t* utt_order, const srx_models_t* models,
+                      double* out_stats, hipStream_t st);
+int srx_generic_mstep(srx_context* h, const double* stats, const srx_priors_t* pr,
+                      int mode, const srx_models_t* models, hipStream_t st);
+
+// Implemented in score_mfma.hip: returns SRX_EUNSUPPORTED when the shape has no
+// matrix-core kernel, so the caller can take the generic path.
+int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
+                   int64_t n_frames, const srx_models_t* models, double* out,
+                   hipStream_t st);

@@ -1,0 +1,269 @@
+"""Generate the golden vectors under tests/golden/ by running the reference.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py [mfcc] [hmm] [folds]
+
+The reference modules are imported as they are.  ``mfcc.py`` imports three
+third-party modules that are absent here and that the code path never uses for
+its result (``sounddevice.wait()``, ``seaborn``, and a ``librosa.feature.mfcc``
+call whose result is discarded, mfcc.py:139); empty placeholder modules with
+those names are put in ``sys.modules`` so the import succeeds.
+
+Only data leaves this script: inputs and the reference's outputs, as .npz.
+The reference's pickled models are NOT read (unpickling executes code).
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+WORDS = ["odessa", "play_music", "stop_music", "turn_off_the_lights",
+         "turn_on_the_lights", "what_time_is_it"]  # np.unique order
+
+
+def _import_reference():
+    sys.path.insert(0, REF)
+    sd = types.ModuleType("sounddevice")
+    sd.wait = lambda *a, **k: None
+    sns = types.ModuleType("seaborn")
+    lib = types.ModuleType("librosa")
+    feat = types.ModuleType("librosa.feature")
+    feat.mfcc = lambda **kw: None
+    lib.feature = feat
+    lib.load = lambda *a, **k: (None, None)
+    sys.modules.update({"sounddevice": sd, "seaborn": sns, "librosa": lib,
+                        "librosa.feature": feat})
+    import matplotlib
+    matplotlib.use("Agg")
+    import mfcc as ref_mfcc
+    import HMM_final as ref_final
+    from my_hmmlearn import hmm as ref_hmm, utils as ref_utils
+    return ref_mfcc, ref_final, ref_hmm, ref_utils
+
+
+def _synthetic_signals():
+    rng = np.random.default_rng(20240601)
+    out = []
+    # 16 kHz, 1.0 s: noise + three sinusoids
+    t = np.arange(16000) / 16000.0
+    s = 0.05 * rng.standard_normal(16000)
+    for f, a in ((220.0, 0.1), (1330.0, 0.05), (3700.0, 0.03)):
+        s += a * np.sin(2 * np.pi * f * t)
+    out.append((s, 16000))
+    # 22.05 kHz, 0.7 s chirp-ish + noise
+    n = int(0.7 * 22050)
+    t = np.arange(n) / 22050.0
+    s = 0.1 * np.sin(2 * np.pi * (300.0 + 2000.0 * t) * t) + 0.02 * rng.standard_normal(n)
+    out.append((s, 22050))
+    # shortest input that still yields one output frame at 16 kHz: T = 5
+    out.append((0.1 * rng.standard_normal(400 + 4 * 160), 16000))
+    # silence then noise: exact-zero mel energies hit the eps floor
+    s = np.concatenate([np.zeros(2000), 0.1 * rng.standard_normal(3000)])
+    out.append((s, 16000))
+    # all-zero signal: constant features, z-score keeps scale 1
+    out.append((np.zeros(2400), 16000))
+    return out
+
+
+def make_mfcc(ref_mfcc, ref_final):
+    from scipy.io import wavfile
+    data = {}
+    sigs = _synthetic_signals()
+    real = ["odessa_5", "play_music_12", "turn_off_the_lights_3", "what_time_is_it_27"]
+    for name in real:
+        sr, s = wavfile.read(f"{REF}/cleaned_audios_3005/{name}.wav")
+        sigs.append((np.asarray(s, dtype=np.float64), sr))
+    with tempfile.TemporaryDirectory() as tmp:
+        for i, (s, sr) in enumerate(sigs):
+            s32 = np.asarray(s, dtype=np.float32)
+            path = os.path.join(tmp, f"sig{i}.wav")
+            wavfile.write(path, sr, s32)
+            cep = ref_mfcc.compute_mfcc(wavfile.read(path)[1], sr)
+            feat = ref_mfcc.calculate_mfcc_for_onerecording(False, path, sample_rate=sr)
+            with np.errstate(all="ignore"):
+                z = ref_final.extract_mfcc_calc(path, sr)
+            data[f"sig{i}"] = s32
+            data[f"sr{i}"] = np.int64(sr)
+            data[f"cep{i}"] = cep            # (T, 13)
+            data[f"feat{i}"] = feat          # (26, T-4)
+            data[f"z{i}"] = z                # (T-4, 26)
+    data["n"] = np.int64(len(sigs))
+    data["fbank1024"] = ref_mfcc.mel_filterbank(1024)
+    data["fbank512"] = ref_mfcc.mel_filterbank(512)
+    np.savez_compressed(os.path.join(OUT, "mfcc_golden.npz"), **data)
+    print("mfcc_golden.npz:", len(sigs), "signals")
+
+
+def _ref_model(ref_hmm, pi, A, mu, var):
+    m = ref_hmm.MyGaussianHMM(n_components=len(pi), implementation="scaling",
+                              verbose=False)
+    m.startprob_ = np.array(pi, dtype=float)
+    m.transmat_ = np.array(A, dtype=float)
+    m.means_ = np.array(mu, dtype=float)
+    m._covars_ = np.array(var, dtype=float)
+    m.n_features = m.means_.shape[1]
+    return m
+
+
+def _stats_arrays(prefix, st, d):
+    d[prefix + "nobs"] = np.int64(st["nobs"])
+    for k, n in (("start", "start"), ("trans", "trans"), ("post", "post"),
+                 ("obs", "obs"), ("obs**2", "obs2")):
+        d[prefix + n] = np.array(st[k])
+
+
+def make_hmm(ref_hmm, ref_utils):
+    rng = np.random.default_rng(7)
+    cases = [
+        ("s3d26", 3, 26, [57, 120, 33, 1, 2, 88], False),
+        ("s8d39", 8, 39, [200, 200, 61, 5], False),
+        ("s16d39", 16, 39, [200, 37, 140], False),
+        ("s3d13", 3, 13, [90, 45, 1], False),
+        ("s5d7lr", 5, 7, [64, 30, 12], True),   # left-to-right, zeros in pi/A
+    ]
+    data = {"cases": np.array([c[0] for c in cases])}
+    for name, S, D, lengths, left_right in cases:
+        pi = rng.dirichlet(np.ones(S))
+        A = rng.dirichlet(np.ones(S), size=S)
+        if left_right:
+            pi = np.zeros(S)
+            pi[0] = 1.0
+            A = np.triu(A) * (np.tril(np.ones((S, S)), 1))
+            A /= A.sum(axis=1, keepdims=True)
+        mu = rng.standard_normal((S, D))
+        var = rng.uniform(0.5, 1.5, (S, D))
+        X = rng.standard_normal((sum(lengths), D))
+        # make the data depend on the states a little so posteriors are not flat
+        X += mu[rng.integers(0, S, size=len(X))] * 0.7
+        m = _ref_model(ref_hmm, pi, A, mu, var)
+        p = name + "_"
+        data[p + "pi"], data[p + "A"], data[p + "mu"], data[p + "var"] = pi, A, mu, var
+        data[p + "X"], data[p + "lengths"] = X, np.array(lengths)
+        data[p + "loglik"] = m._log_multivariate_normal_density_diag(X, m.means_, m._covars_)
+        subs = ref_utils.split_X_lengths(X, lengths)
+        data[p + "utt_logprob"] = np.array([m.score(x) for x in subs])
+        data[p + "score_all"] = np.float64(m.score(X, lengths))
+        # lattices of the first utterance
+        B, lp, g, al, be = m.fit_scaling(subs[0])
+        data[p + "alpha0"], data[p + "beta0"], data[p + "gamma0"] = al, be, g
+        data[p + "xi0"] = ref_utils.compute_scaling_xi_sum(al, m.transmat_, be, B)
+        st, lp = m.do_estep(X, np.array(lengths))
+        _stats_arrays(p + "st_", st, data)
+        data[p + "logprob"] = np.float64(lp)
+        # transitions-only M-step (what fit() calls, hmm.py:213)
+        m1 = _ref_model(ref_hmm, pi, A, mu, var)
+        m1.do_em_mstep(st)
+        data[p + "em_pi"], data[p + "em_A"] = m1.startprob_, m1.transmat_
+        # full M-step (do_mstep, hmm.py:165)
+        m2 = _ref_model(ref_hmm, pi, A, mu, var)
+        m2.do_mstep(st)
+        data[p + "m_pi"], data[p + "m_A"] = m2.startprob_, m2.transmat_
+        data[p + "m_mu"], data[p + "m_var"] = m2.means_, m2._covars_
+        # second EM iteration from the re-estimated model
+        st2, lp2 = m2.do_estep(X, np.array(lengths))
+        _stats_arrays(p + "st2_", st2, data)
+        data[p + "logprob2"] = np.float64(lp2)
+        m2.do_mstep(st2)
+        data[p + "m2_pi"], data[p + "m2_A"] = m2.startprob_, m2.transmat_
+        data[p + "m2_mu"], data[p + "m2_var"] = m2.means_, m2._covars_
+        # Viterbi through utils.viterbi called directly with log inputs
+        with np.errstate(divide="ignore"):
+            lpi, lA = np.log(pi), np.log(A)
+        vlp, vpath = [], []
+        for x in subs:
+            ll = m._log_multivariate_normal_density_diag(x, m.means_, m._covars_)
+            a, b = ref_utils.viterbi(lpi, lA, ll)
+            vlp.append(a)
+            vpath.append(b)
+        data[p + "vit_logprob"] = np.array(vlp)
+        data[p + "vit_path"] = np.concatenate(vpath).astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, "hmm_golden.npz"), **data)
+    print("hmm_golden.npz:", [c[0] for c in cases])
+
+
+def fold_init(X, S):
+    """Deterministic initial parameters for the fold fixtures (the reference's
+    own init draws from unseeded global RNG state, hmm.py:120-127)."""
+    pi = np.full(S, 1.0 / S)
+    A = np.full((S, S), 0.2 / (S - 1))
+    np.fill_diagonal(A, 0.8)
+    idx = np.linspace(0, len(X) - 1, S + 2).astype(int)[1:-1]
+    mu = X[idx].copy()
+    var = np.tile(np.var(X, axis=0) + 1e-3, (S, 1))
+    return pi, A, mu, var
+
+
+def make_folds(ref_final, ref_hmm, n_iter=8):
+    import contextlib
+    import io
+    names = sorted(f[:-4] for f in os.listdir(f"{REF}/cleaned_audios_3005")
+                   if f.endswith(".wav") and not f.startswith("audio_"))
+    feats, lengths = [], []
+    for nme in names:
+        with np.errstate(all="ignore"):
+            z = ref_final.extract_mfcc_calc(f"{REF}/cleaned_audios_3005/{nme}.wav", 22050)
+        feats.append(z.astype(np.float32))
+        lengths.append(len(z))
+    offs = np.concatenate([[0], np.cumsum(lengths)])
+    index = {n: i for i, n in enumerate(names)}
+    data = {"names": np.array(names), "feats": np.vstack(feats),
+            "lengths": np.array(lengths), "words": np.array(WORDS),
+            "n_iter": np.int64(n_iter)}
+
+    def utt(n):
+        i = index[n]
+        return data["feats"][offs[i]:offs[i + 1]].astype(np.float64)
+
+    def word_of(n):
+        return n[: n.rfind("_")]
+
+    for fold in range(1, 6):
+        with open(f"{REF}/Folds/train {fold}.txt") as f:
+            train = [l.strip()[:-4] for l in f if l.strip()]
+        with open(f"{REF}/Folds/validation {fold}.txt") as f:
+            val = [l.strip()[:-4] for l in f if l.strip()]
+        data[f"f{fold}_train"] = np.array(train)
+        data[f"f{fold}_val"] = np.array(val)
+        models = {}
+        for w in WORDS:
+            xs = [utt(n) for n in train if word_of(n) == w]
+            X = np.vstack(xs)
+            L = np.array([len(x) for x in xs])
+            pi, A, mu, var = fold_init(X, 3)
+            m = _ref_model(ref_hmm, pi, A, mu, var)
+            hist = []
+            for _ in range(n_iter):
+                st, lp = m.do_estep(X, L)
+                m.do_mstep(st)
+                hist.append(lp)
+            models[w] = m
+            p = f"f{fold}_{w}_"
+            data[p + "pi"], data[p + "A"] = m.startprob_, m.transmat_
+            data[p + "mu"], data[p + "var"] = m.means_, m._covars_
+            data[p + "hist"] = np.array(hist)
+        scores = np.array([[models[w].score(utt(n)) for w in WORDS] for n in val])
+        pred = [max({w: s for w, s in zip(WORDS, row)}, key=dict(zip(WORDS, row)).get)
+                for row in scores]
+        right = sum(p == word_of(n) for p, n in zip(pred, val))
+        data[f"f{fold}_scores"] = scores
+        data[f"f{fold}_pred"] = np.array(pred)
+        data[f"f{fold}_right"] = np.int64(right)
+        print(f"fold {fold}: right {right}/{len(val)}", flush=True)
+    np.savez_compressed(os.path.join(OUT, "folds_golden.npz"), **data)
+    print("folds_golden.npz written")
+
+
+if __name__ == "__main__":
+    what = set(sys.argv[1:]) or {"mfcc", "hmm", "folds"}
+    ref_mfcc, ref_final, ref_hmm, ref_utils = _import_reference()
+    if "mfcc" in what:
+        make_mfcc(ref_mfcc, ref_final)
+    if "hmm" in what:
+        make_hmm(ref_hmm, ref_utils)
+    if "folds" in what:
+        make_folds(ref_final, ref_hmm)

@@ -1,0 +1,98 @@
+"""Pin the CPU oracle to the reference's own outputs (tests/golden/*.npz were
+produced by importing the reference, see tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+
+from oracle import hmm_oracle as ho
+from oracle import mfcc_oracle as mo
+from conftest import golden_params
+
+CASES = ["s3d26", "s8d39", "s16d39", "s3d13", "s5d7lr"]
+
+
+def _cfg(sr):
+    return mo.MfccConfig(sample_rate=int(sr))
+
+
+def test_mel_filterbank_matches_reference(mfcc_golden):
+    np.testing.assert_array_equal(mo.mel_filterbank(1024), mfcc_golden["fbank1024"])
+    np.testing.assert_array_equal(mo.mel_filterbank(512), mfcc_golden["fbank512"])
+    assert np.count_nonzero(mfcc_golden["fbank1024"]) == 944
+
+
+@pytest.mark.parametrize("i", range(9))
+def test_mfcc_oracle_matches_reference(mfcc_golden, i):
+    g = mfcc_golden
+    sig, sr = g[f"sig{i}"].astype(np.float64), int(g[f"sr{i}"])
+    cfg = _cfg(sr)
+    cep = mo.cepstra(sig, cfg)
+    assert cep.shape == g[f"cep{i}"].shape
+    np.testing.assert_allclose(cep, g[f"cep{i}"], rtol=1e-9, atol=1e-9)
+    feat = mo.features(sig, cfg)
+    np.testing.assert_allclose(feat.T, g[f"feat{i}"], rtol=1e-9, atol=1e-9)
+    z = mo.extract(sig, cfg)
+    assert z.shape == g[f"z{i}"].shape
+    np.testing.assert_allclose(z, g[f"z{i}"], rtol=1e-7, atol=1e-7)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("loops", [True, False])
+def test_hmm_oracle_matches_reference(hmm_golden, case, loops):
+    g, p = hmm_golden, case + "_"
+    prm = golden_params(g, case)
+    X, L = g[p + "X"], g[p + "lengths"]
+    np.testing.assert_allclose(ho.log_density_diag(X, prm.means, prm.covars),
+                               g[p + "loglik"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(ho.score(prm, X, L, loops=loops), g[p + "utt_logprob"],
+                               rtol=1e-12)
+    st, lps = ho.estep(prm, X, L, loops=loops)
+    assert st["nobs"] == int(g[p + "st_nobs"])
+    for k, n in (("start", "start"), ("trans", "trans"), ("post", "post"),
+                 ("obs", "obs"), ("obs**2", "obs2")):
+        np.testing.assert_allclose(st[k], g[p + "st_" + n], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(lps.sum(), g[p + "logprob"], rtol=1e-12)
+    q = ho.mstep_transitions(prm, st)
+    np.testing.assert_allclose(q.pi, g[p + "em_pi"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(q.A, g[p + "em_A"], rtol=1e-12, atol=1e-15)
+    q = ho.mstep_full(prm, st)
+    np.testing.assert_allclose(q.pi, g[p + "m_pi"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(q.A, g[p + "m_A"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(q.means, g[p + "m_mu"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(q.covars, g[p + "m_var"], rtol=1e-9, atol=1e-12)
+    st2, lps2 = ho.estep(q, X, L, loops=loops)
+    np.testing.assert_allclose(lps2.sum(), g[p + "logprob2"], rtol=1e-11)
+    q2 = ho.mstep_full(q, st2)
+    np.testing.assert_allclose(q2.means, g[p + "m2_mu"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(q2.covars, g[p + "m2_var"], rtol=1e-8, atol=1e-11)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_lattices_match_reference(hmm_golden, case):
+    g, p = hmm_golden, case + "_"
+    prm = golden_params(g, case)
+    x = g[p + "X"][: int(g[p + "lengths"][0])]
+    B = np.exp(ho.log_density_diag(x, prm.means, prm.covars))
+    for fwd, bwd, xis in ((ho.forward_scaling_loops, ho.backward_scaling_loops, ho.xi_sum_loops),
+                          (ho.forward_scaling_vec, ho.backward_scaling_vec, ho.xi_sum_vec)):
+        lp, al, c = fwd(prm.pi, prm.A, B)
+        be = bwd(prm.pi, prm.A, B, c)
+        np.testing.assert_allclose(al, g[p + "alpha0"], rtol=1e-11, atol=1e-300)
+        np.testing.assert_allclose(be, g[p + "beta0"], rtol=1e-10, atol=1e-300)
+        np.testing.assert_allclose(ho.posteriors(al, be), g[p + "gamma0"], rtol=1e-10, atol=1e-300)
+        np.testing.assert_allclose(xis(al, prm.A, be, B), g[p + "xi0"], rtol=1e-10, atol=1e-300)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_viterbi_matches_reference(hmm_golden, case):
+    g, p = hmm_golden, case + "_"
+    prm = golden_params(g, case)
+    lp, path = ho.viterbi(prm, g[p + "X"], g[p + "lengths"])
+    np.testing.assert_allclose(lp, g[p + "vit_logprob"], rtol=1e-13)
+    np.testing.assert_array_equal(path, g[p + "vit_path"])
+
+
+def test_split_lengths_error():
+    with pytest.raises(ValueError):
+        ho.split_lengths(np.zeros((5, 2)), [2, 2])
+    with pytest.raises(ValueError):
+        ho.forward_scaling_loops(np.ones(2) / 2, np.ones((3, 3)) / 3, np.ones((4, 3)))
