@@ -1,0 +1,18 @@
+"""MI355X-native MFCC + diagonal-Gaussian HMM hot path (scoring, Baum-Welch,
+Viterbi) behind the call surface of Tejashreenk/Speech-Recognition.
+
+    from speech_recognition_amd import hmm, mfcc, recognizer, parallel
+    model = hmm.MyGaussianHMM(n_components=3, tol=1e-4, n_iter=2000)
+    model.fit(X, lengths); model.score(X)
+
+All arithmetic runs in libsrx.so (hand-written HIP for gfx950, C ABI in
+include/srx.h); importing the package fails if that library is not built.
+"""
+from . import _lib                      # noqa: F401  (raises if libsrx.so is missing)
+from . import runtime, hmm, mfcc, recognizer, parallel, SpeechUtil   # noqa: F401
+from .hmm import MyGaussianHMM, GaussianHMM, ConvergenceMonitor        # noqa: F401
+from .runtime import Context, HMMBank, Ragged, MfccPlan                 # noqa: F401
+
+HMM_final = recognizer   # the reference's module name for the same functions
+
+__version__ = "0.1.0"

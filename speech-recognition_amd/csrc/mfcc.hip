@@ -388,8 +388,8 @@ int srx_mfcc_batch(srx_handle_t h, srx_mfcc_plan_t p, const void* audio, int dty
     SRX_REQUIRE(dtype == SRX_F32 || dtype == SRX_F64, "srx_mfcc_batch: unknown dtype %d", dtype);
     SRX_REQUIRE(n_utts >= 0 && n_samples >= 0, "srx_mfcc_batch: negative size");
     if (n_utts == 0 || n_samples == 0) return SRX_OK;
-    SRX_REQUIRE(audio && sample_offsets && frame_offsets && out_feats,
-                "srx_mfcc_batch: NULL buffer");
+    SRX_REQUIRE(audio && sample_offsets && frame_offsets, "srx_mfcc_batch: NULL buffer");
+    if (out_feats == nullptr) return SRX_OK;   // no utterance yields a frame
     SRX_HIP(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     const srx_mfcc_cfg_t& c = p->cfg;

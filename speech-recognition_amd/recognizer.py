@@ -1,0 +1,139 @@
+"""Train / score harness with the reference's function names (HMM_final.py).
+
+``extract_mfcc_calc`` (HMM_final.py:18), ``train_hmm`` (:26), ``recognize``
+(:49), ``load_models`` (:71), ``test_trained_model`` (:134) keep their
+arguments and results.  Under them everything is batched: all utterances of a
+call go through one front-end launch and one scoring launch against all word
+models at once (the reference loops over files and over the six models).
+"""
+import os
+import pickle
+
+import numpy as np
+
+from . import SpeechUtil as su
+from . import mfcc as fe
+from .hmm import MyGaussianHMM
+from .runtime import Context, HMMBank, Ragged
+
+WORDS = ["play_music", "stop_music", "turn_off_the_lights", "turn_on_the_lights",
+         "what_time_is_it", "odessa"]          # HMM_final.py:64
+
+
+def extract_mfcc_calc(audio_path, sample_rate, n_mfcc=13, dtype="float64"):
+    """(T-4, 26) z-scored MFCC+delta of one WAV file, HMM_final.py:18-23."""
+    signal = su.read_recording(str(audio_path).replace(".wav", ""), sample_rate)
+    return fe.extract_features(signal, sample_rate, dtype=dtype)
+
+
+def extract_many(audio_paths, sample_rate, dtype="float64"):
+    """Features of many files in one launch -> (packed features, lengths)."""
+    sigs = [su.read_recording(str(p).replace(".wav", ""), sample_rate) for p in audio_paths]
+    return fe.extract_batch(sigs, sample_rate, dtype=dtype)
+
+
+def train_hmm(models, audio_files, labels, sample_rate, i=-1, *, model_dir="SavedModels",
+              n_components=3, tol=1e-4, n_iter=2000, save=True, verbose=True, **hmm_kw):
+    """One model per distinct label, trained on that label's files and stored in
+    ``models[label]`` (and pickled), HMM_final.py:26-46."""
+    print("Training started ...")
+    labels = np.asarray(labels)
+    feats, lengths = extract_many(audio_files, sample_rate, dtype=hmm_kw.get("dtype", "float64"))
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    for label in np.unique(labels):
+        idx = [k for k in range(len(labels)) if labels[k] == label]
+        X = np.vstack([feats[off[k]:off[k + 1]] for k in idx])
+        L = [int(lengths[k]) for k in idx]
+        model = MyGaussianHMM(n_components=n_components, tol=tol, n_iter=n_iter,
+                              implementation="scaling", verbose=verbose, **hmm_kw)
+        model.fit(X, L)
+        models[label] = model
+        if save:
+            os.makedirs(model_dir, exist_ok=True)
+            name = f"{label}_hmm_model.pkl" if i == -1 else f"{label}_{i}_hmm_model.pkl"
+            path = os.path.join(model_dir, name)
+            with open(path, "wb") as f:
+                pickle.dump(model, f)
+            print(f"Model for {label} saved at {path}")
+
+
+def score_matrix(models, feats, lengths, dtype="float64", ctx=None):
+    """(U, n_models) log-likelihoods in ``models`` insertion order: the dict
+    comprehension of HMM_final.py:51 for every utterance at once."""
+    ctx = ctx or Context.default()
+    ms = list(models.values())
+    shapes = {(m.n_components, m.means_.shape[1]) for m in ms}
+    data = Ragged(ctx, feats, lengths, dtype=dtype)
+    if len(shapes) == 1:
+        return HMMBank.from_models(ctx, ms).score(data).cpu().numpy()
+    cols = [HMMBank.from_models(ctx, [m]).score(data).cpu().numpy()[:, 0] for m in ms]
+    return np.stack(cols, axis=1)
+
+
+def recognize_many(models, audio_paths, sample_rate, dtype="float64"):
+    feats, lengths = extract_many(audio_paths, sample_rate, dtype=dtype)
+    scores = score_matrix(models, feats, lengths, dtype=dtype)
+    names = list(models.keys())
+    # max(scores, key=scores.get): the first best key in insertion order
+    return [names[int(np.argmax(row))] for row in scores], scores
+
+
+def recognize(models, audio_path, sample_rate):
+    """Label whose model gives the utterance the highest log-likelihood,
+    HMM_final.py:49-52."""
+    return recognize_many(models, [audio_path], sample_rate)[0][0]
+
+
+def load_models(model_dir="models"):
+    """Unpickle every ``*_hmm_model.pkl`` of a directory, HMM_final.py:71-85.
+    Only for files written by ``train_hmm`` of this package."""
+    models = {}
+    for file in os.listdir(model_dir):
+        if file.endswith("_hmm_model.pkl"):
+            label = file.replace("_hmm_model.pkl", "")
+            path = os.path.join(model_dir, file)
+            with open(path, "rb") as f:
+                models[label] = pickle.load(f)
+            print(f"Model for {label} loaded from {path}")
+    return models
+
+
+def train_using_all_files(models, directory="cleaned_audios_3005", sample_rate=22050, n_files=25,
+                          **kw):
+    """HMM_final.py:59-69 with the module-level ``models`` made an argument."""
+    audio_files, labels = [], []
+    for word in WORDS:
+        for k in range(n_files):
+            audio_files.append(f"{directory}/{word}_{k + 1}.wav")
+            labels.append(word)
+    train_hmm(models, audio_files, labels, sample_rate, **kw)
+
+
+def _word_of(sample):
+    stem = sample.replace(".wav", "")
+    return stem[: stem.rfind("_")]
+
+
+def test_trained_model(models, directory, sample_rate, folds_dir="Folds", lists=None):
+    """Score the validation lists and print right / wrong per list,
+    HMM_final.py:134-165 (fold 1 is listed twice there).  Returns the
+    (right, wrong) pairs."""
+    lists = lists or ["validation 1.txt", "validation 1.txt", "validation 2.txt",
+                      "validation 3.txt", "validation 4.txt", "validation 5.txt"]
+    results = []
+    for name in lists:
+        with open(os.path.join(folds_dir, name)) as f:
+            samples = [l.strip() for l in f if l.strip()]
+        print(name)
+        pred, _ = recognize_many(models, [f"{directory}/{s}" for s in samples], sample_rate)
+        right = 0
+        for s, p in zip(samples, pred):
+            print(_word_of(s))
+            print(p)
+            right += int(p == _word_of(s))
+        print(f"right: {right}; wrong: {len(samples) - right}")
+        results.append((right, len(samples) - right))
+    return results
+
+
+test_trained_model.__test__ = False   # not a pytest test

@@ -1,0 +1,307 @@
+"""Device-side plumbing: one libsrx context per GPU, torch tensors as buffers.
+
+torch is used for device memory, streams and (in parallel.py) the process
+group only; every arithmetic step of the path is a libsrx kernel.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+_DTYPES = {"float32": (torch.float32, _lib.SRX_F32, np.float32),
+           "float64": (torch.float64, _lib.SRX_F64, np.float64)}
+
+
+def dtype_info(dtype):
+    key = np.dtype(dtype).name if not isinstance(dtype, str) else dtype
+    if key not in _DTYPES:
+        raise ValueError(f"dtype must be float32 or float64, got {dtype!r}")
+    return _DTYPES[key]
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "speech_recognition_amd needs a visible MI355X: torch.cuda.is_available() is "
+            "False and there is no CPU fallback")
+
+
+class Context:
+    """One per GPU / rank (srx_create)."""
+
+    _lock = threading.Lock()
+    _default = {}
+
+    def __init__(self, device=None):
+        _require_gpu()
+        if device is None:
+            device = torch.cuda.current_device()
+        self.index = int(torch.device("cuda", device).index if not isinstance(device, int) else device)
+        self.device = torch.device("cuda", self.index)
+        h = C.c_void_p()
+        check(lib.srx_create(self.index, C.byref(h)), "srx_create")
+        self._h = h
+
+    @classmethod
+    def default(cls, device=None):
+        _require_gpu()
+        idx = torch.cuda.current_device() if device is None else int(device)
+        with cls._lock:
+            if idx not in cls._default:
+                cls._default[idx] = cls(idx)
+            return cls._default[idx]
+
+    @property
+    def handle(self):
+        return self._h
+
+    def stream_ptr(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace_bytes(self):
+        return int(lib.srx_workspace_bytes(self._h))
+
+    def tensor(self, array, dtype=None):
+        """Host array / tensor -> contiguous device tensor."""
+        if isinstance(array, torch.Tensor):
+            t = array.to(self.device)
+            if dtype is not None:
+                t = t.to(dtype)
+            return t.contiguous()
+        a = np.ascontiguousarray(array)
+        t = torch.from_numpy(a).to(self.device)
+        if dtype is not None:
+            t = t.to(dtype)
+        return t
+
+    def close(self):
+        if self._h:
+            lib.srx_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()
+
+
+def offsets_from_lengths(lengths, total=None):
+    """lengths -> int64 offsets[U+1]; the reference's length check
+    (my_hmmlearn/utils.py:284-286)."""
+    lengths = np.asarray(lengths, dtype=np.int64).reshape(-1)
+    if (lengths < 0).any():
+        raise ValueError("negative utterance length")
+    off = np.zeros(len(lengths) + 1, dtype=np.int64)
+    np.cumsum(lengths, out=off[1:])
+    if total is not None and off[-1] != total:
+        raise ValueError(f"lengths array {lengths} doesn't sum to {total} samples")
+    return off
+
+
+class Ragged:
+    """Packed frames [n_frames, D] on the device plus utterance offsets."""
+
+    def __init__(self, ctx, X, lengths=None, dtype="float32", offsets=None):
+        tdt, self.code, _ = dtype_info(dtype)
+        self.ctx = ctx
+        if isinstance(X, torch.Tensor):
+            if X.dim() != 2:
+                raise ValueError("X must be 2-D (n_frames, n_features)")
+            self.X = X.to(ctx.device, tdt).contiguous()
+        else:
+            X = np.asarray(X)
+            if X.ndim != 2:
+                raise ValueError("X must be 2-D (n_frames, n_features)")
+            self.X = ctx.tensor(X, tdt)
+        self.n_frames, self.D = int(self.X.shape[0]), int(self.X.shape[1])
+        if offsets is not None:
+            self.offsets_host = None
+            self.offsets = offsets.to(ctx.device, torch.int64).contiguous()
+            self.U = int(self.offsets.numel()) - 1
+        else:
+            if lengths is None:
+                lengths = [self.n_frames]
+            off = offsets_from_lengths(lengths, self.n_frames)
+            self.offsets_host = off
+            self.offsets = ctx.tensor(off)
+            self.U = len(off) - 1
+
+
+class HMMBank:
+    """n_models diagonal-Gaussian HMMs with common (S, D), parameters resident
+    on the device as float64 (srx_models_t)."""
+
+    def __init__(self, ctx, startprob, transmat, means, covars):
+        self.ctx = ctx
+        sp = np.asarray(startprob, dtype=np.float64)
+        A = np.asarray(transmat, dtype=np.float64)
+        mu = np.asarray(means, dtype=np.float64)
+        cv = np.asarray(covars, dtype=np.float64)
+        if sp.ndim == 1:
+            sp, A, mu, cv = sp[None], A[None], mu[None], cv[None]
+        M, S = sp.shape
+        if A.shape != (M, S, S) or mu.ndim != 3 or mu.shape[:2] != (M, S) or cv.shape != mu.shape:
+            raise ValueError("Shape mismatch")
+        if cv.ndim != 3:
+            raise ValueError("'diag' covars must have shape (n_components, n_dim)")
+        if np.any(cv <= 0):
+            raise ValueError("'diag' covars must be positive")
+        self.M, self.S, self.D = M, S, int(mu.shape[2])
+        self.startprob = ctx.tensor(sp)
+        self.transmat = ctx.tensor(A)
+        self.means = ctx.tensor(mu)
+        self.covars = ctx.tensor(cv)
+        self._struct = _lib.Models(M, S, self.D, self.startprob.data_ptr(),
+                                   self.transmat.data_ptr(), self.means.data_ptr(),
+                                   self.covars.data_ptr())
+        self.stats_size = int(lib.srx_stats_size(S, self.D))
+
+    @classmethod
+    def from_models(cls, ctx, models):
+        """models: sequence of objects with startprob_/transmat_/means_/_covars_."""
+        return cls(ctx, np.stack([m.startprob_ for m in models]),
+                   np.stack([m.transmat_ for m in models]),
+                   np.stack([m.means_ for m in models]),
+                   np.stack([m._covars_ for m in models]))
+
+    def _check(self, data):
+        if data.D != self.D:
+            raise ValueError(
+                f"Unexpected number of dimensions, got {data.D} but expected {self.D}")
+
+    # -- kernels ---------------------------------------------------------
+    def emission_loglik(self, data):
+        self._check(data)
+        out = torch.empty((data.n_frames, self.M * self.S), dtype=data.X.dtype, device=self.ctx.device)
+        check(lib.srx_emission_loglik(self.ctx.handle, ptr(data.X), data.code, data.n_frames,
+                                      C.byref(self._struct), ptr(out), self.ctx.stream_ptr()),
+              "srx_emission_loglik")
+        return out
+
+    def score(self, data, out=None, generic=False):
+        """(U, M) forward log-probabilities, float64, on the device."""
+        self._check(data)
+        if out is None:
+            out = torch.empty((data.U, self.M), dtype=torch.float64, device=self.ctx.device)
+        fn = lib.srx_forward_score_generic if generic else lib.srx_forward_score
+        check(fn(self.ctx.handle, ptr(data.X), data.code, ptr(data.offsets), data.U, data.n_frames,
+                 C.byref(self._struct), ptr(out), self.ctx.stream_ptr()), "srx_forward_score")
+        return out
+
+    def viterbi(self, data, utt_model=None):
+        self._check(data)
+        path = torch.empty((data.n_frames,), dtype=torch.int32, device=self.ctx.device)
+        lp = torch.empty((data.U,), dtype=torch.float64, device=self.ctx.device)
+        um = self.ctx.tensor(np.asarray(utt_model, dtype=np.int32)) if utt_model is not None and \
+            not isinstance(utt_model, torch.Tensor) else utt_model
+        check(lib.srx_viterbi(self.ctx.handle, ptr(data.X), data.code, ptr(data.offsets), data.U,
+                              data.n_frames, ptr(um), C.byref(self._struct), ptr(path), ptr(lp),
+                              self.ctx.stream_ptr()), "srx_viterbi")
+        return lp, path
+
+    def estep(self, data, utt_model=None, utt_order=None, out=None):
+        """Packed statistics (M, stats_size) float64 on the device."""
+        self._check(data)
+        if out is None:
+            out = torch.empty((self.M, self.stats_size), dtype=torch.float64, device=self.ctx.device)
+        check(lib.srx_estep_stats(self.ctx.handle, ptr(data.X), data.code, ptr(data.offsets), data.U,
+                                  data.n_frames, ptr(utt_model), ptr(utt_order),
+                                  C.byref(self._struct), ptr(out), self.ctx.stream_ptr()),
+              "srx_estep_stats")
+        return out
+
+    def mstep(self, stats, priors=None, mode="full"):
+        pr = priors if priors is not None else _lib.Priors(1.0, 1.0, 0.0, 0.0, 1e-2, 1.0)
+        code = {"full": _lib.SRX_MSTEP_FULL,
+                "transitions_only": _lib.SRX_MSTEP_TRANSITIONS_ONLY}[mode]
+        check(lib.srx_mstep(self.ctx.handle, ptr(stats), C.byref(pr), code, C.byref(self._struct),
+                            self.ctx.stream_ptr()), "srx_mstep")
+
+    # -- host views --------------------------------------------------------
+    def params_host(self):
+        return (self.startprob.cpu().numpy(), self.transmat.cpu().numpy(),
+                self.means.cpu().numpy(), self.covars.cpu().numpy())
+
+    def unpack_stats(self, stats):
+        """Packed record(s) -> list of dicts with the reference's keys
+        (initialize_sufficient_statistics, my_hmmlearn/hmm.py:224-235) plus
+        'logprob'."""
+        s = stats.detach().cpu().numpy().reshape(self.M, -1)
+        S, D = self.S, self.D
+        out = []
+        for r in s:
+            o = 2
+            d = {"nobs": int(round(r[0])), "logprob": float(r[1])}
+            d["start"] = r[o:o + S].copy(); o += S
+            d["trans"] = r[o:o + S * S].reshape(S, S).copy(); o += S * S
+            d["post"] = r[o:o + S].copy(); o += S
+            d["obs"] = r[o:o + S * D].reshape(S, D).copy(); o += S * D
+            d["obs**2"] = r[o:o + S * D].reshape(S, D).copy()
+            out.append(d)
+        return out
+
+
+class MfccPlan:
+    """Front-end tables on the device for one configuration (srx_mfcc_plan_*)."""
+
+    def __init__(self, ctx, sample_rate, frame_size=0.025, frame_stride=0.01, nfft=1024, n_mel=26,
+                 mel_sample_rate=16000, n_ceps=13, delta_order=1, delta_n=2, log_mult=20.0,
+                 zscore=True):
+        self.ctx = ctx
+        # mfcc.py:18-19: float products truncated where they are used
+        frame_len, hop = int(frame_size * sample_rate), int(frame_stride * sample_rate)
+        self.cfg = _lib.MfccCfg(int(sample_rate), frame_len, hop, int(nfft), int(n_mel),
+                                int(mel_sample_rate), int(n_ceps), int(delta_order), int(delta_n),
+                                int(bool(zscore)), float(log_mult))
+        self.n_feat = int(n_ceps) * (1 + int(delta_order))
+        p = C.c_void_p()
+        check(lib.srx_mfcc_plan_create(ctx.handle, C.byref(self.cfg), C.byref(p)),
+              "srx_mfcc_plan_create")
+        self._p = p
+
+    def out_frames(self, n_samples):
+        return int(lib.srx_mfcc_out_frames(C.byref(self.cfg), int(n_samples)))
+
+    def run(self, audio, sample_offsets_host, dtype="float32", out=None):
+        """audio: packed 1-D device tensor (or host array); returns
+        (features [sum T, n_feat] on the device, frame offsets host int64)."""
+        tdt, code, _ = dtype_info(dtype)
+        so = np.asarray(sample_offsets_host, dtype=np.int64)
+        a = self.ctx.tensor(audio, tdt).reshape(-1)
+        if so[-1] != a.numel():
+            raise ValueError(f"sample offsets end at {so[-1]} but audio has {a.numel()} samples")
+        lens = np.diff(so)
+        L, hop, dn = self.cfg.frame_len, self.cfg.hop, self.cfg.delta_n
+        raw = np.where(lens >= L, (lens - L) // hop + 1, 0)
+        outf = raw if self.cfg.delta_order == 0 else np.maximum(raw - 2 * dn, 0)
+        fo = np.zeros(len(lens) + 1, dtype=np.int64)
+        np.cumsum(outf, out=fo[1:])
+        if out is None:
+            out = torch.empty((int(fo[-1]), self.n_feat), dtype=tdt, device=self.ctx.device)
+        if fo[-1] == 0:
+            return out, fo
+        so_d, fo_d = self.ctx.tensor(so), self.ctx.tensor(fo)
+        check(lib.srx_mfcc_batch(self.ctx.handle, self._p, ptr(a), code, ptr(so_d), len(lens),
+                                 int(so[-1]), ptr(out), ptr(fo_d), self.ctx.stream_ptr()),
+              "srx_mfcc_batch")
+        # the offset tensors must outlive the asynchronous kernels
+        self._keep = (a, so_d, fo_d)
+        return out, fo
+
+    def close(self):
+        if self._p:
+            lib.srx_mfcc_plan_destroy(self._p)
+            self._p = C.c_void_p()
+
+
+def filterbank_host(nfft, mel_sample_rate=16000, n_mel=26):
+    """Dense filter matrix as libsrx builds it (no GPU needed)."""
+    cfg = _lib.MfccCfg(16000, 400, 160, int(nfft), int(n_mel), int(mel_sample_rate),
+                       min(13, int(n_mel)), 1, 2, 1, 20.0)
+    out = np.zeros((n_mel, nfft // 2 + 1), dtype=np.float64)
+    check(lib.srx_mfcc_filterbank_host(C.byref(cfg), out.ctypes.data_as(C.c_void_p)),
+          "srx_mfcc_filterbank_host")
+    return out

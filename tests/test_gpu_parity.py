@@ -1,0 +1,287 @@
+"""Parity of the HIP path (through the C ABI) with the reference's outputs
+(tests/golden) and with the CPU oracle on seeded inputs.
+
+Tolerances: float64 is the validation arithmetic and must agree to rounding;
+float32 must meet 1e-4 relative on log-likelihoods / MFCCs and 1e-5 relative
+on re-estimated parameters (transition/start probabilities: absolute 1e-6,
+they can be arbitrarily small)."""
+import numpy as np
+import pytest
+
+from conftest import golden_params
+from oracle import hmm_oracle as ho
+from oracle import mfcc_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["s3d26", "s8d39", "s16d39", "s3d13", "s5d7lr"]
+
+
+@pytest.fixture(scope="module")
+def sra():
+    import speech_recognition_amd as s
+    return s
+
+
+@pytest.fixture(scope="module")
+def ctx(sra):
+    return sra.Context.default()
+
+
+def _bank(sra, ctx, prm_list):
+    return sra.HMMBank(ctx, np.stack([p.pi for p in prm_list]), np.stack([p.A for p in prm_list]),
+                       np.stack([p.means for p in prm_list]), np.stack([p.covars for p in prm_list]))
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-11), ("float32", 2e-5)])
+def test_emission_and_score_match_reference(sra, ctx, hmm_golden, case, dtype, tol):
+    g, p = hmm_golden, case + "_"
+    prm = golden_params(g, case)
+    bank = _bank(sra, ctx, [prm])
+    data = sra.Ragged(ctx, g[p + "X"], g[p + "lengths"], dtype=dtype)
+    ll = bank.emission_loglik(data).cpu().numpy()
+    np.testing.assert_allclose(ll, g[p + "loglik"], rtol=tol, atol=tol * 10)
+    for generic in (False, True):
+        sc = bank.score(data, generic=generic).cpu().numpy()[:, 0]
+        assert _rel(sc, g[p + "utt_logprob"]) < (1e-4 if dtype == "float32" else 1e-11)
+        if dtype == "float32":   # far inside the 1e-4 bar in practice
+            assert _rel(sc, g[p + "utt_logprob"]) < 5e-6
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_estep_and_mstep_match_reference(sra, ctx, hmm_golden, case, dtype):
+    g, p = hmm_golden, case + "_"
+    prm = golden_params(g, case)
+    bank = _bank(sra, ctx, [prm])
+    data = sra.Ragged(ctx, g[p + "X"], g[p + "lengths"], dtype=dtype)
+    stats = bank.estep(data)
+    st = bank.unpack_stats(stats)[0]
+    rt = 1e-9 if dtype == "float64" else 2e-5
+    assert st["nobs"] == int(g[p + "st_nobs"])
+    assert abs(st["logprob"] - float(g[p + "logprob"])) < rt * abs(float(g[p + "logprob"]))
+    for k, n in (("start", "start"), ("trans", "trans"), ("post", "post"), ("obs", "obs"),
+                 ("obs**2", "obs2")):
+        ref = g[p + "st_" + n]
+        np.testing.assert_allclose(st[k], ref, rtol=rt, atol=rt * max(1.0, np.abs(ref).max()))
+    # M-step on the device from the device statistics
+    bank.mstep(stats, mode="full")
+    sp, A, mu, cv = bank.params_host()
+    pt = 1e-9 if dtype == "float64" else 1e-5
+    np.testing.assert_allclose(sp[0], g[p + "m_pi"], rtol=pt, atol=1e-6 if dtype == "float32" else 1e-13)
+    np.testing.assert_allclose(A[0], g[p + "m_A"], rtol=pt, atol=1e-6 if dtype == "float32" else 1e-13)
+    np.testing.assert_allclose(mu[0], g[p + "m_mu"], rtol=pt, atol=pt)
+    np.testing.assert_allclose(cv[0], g[p + "m_var"], rtol=pt, atol=pt)
+    # second iteration from the re-estimated model
+    stats2 = bank.estep(data)
+    lp2 = float(stats2[0, 1].item())
+    assert abs(lp2 - float(g[p + "logprob2"])) < (1e-9 if dtype == "float64" else 1e-5) * abs(lp2)
+    bank.mstep(stats2, mode="full")
+    sp, A, mu, cv = bank.params_host()
+    np.testing.assert_allclose(mu[0], g[p + "m2_mu"], rtol=pt * 5, atol=pt * 5)
+    np.testing.assert_allclose(cv[0], g[p + "m2_var"], rtol=pt * 5, atol=pt * 5)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_transitions_only_mstep(sra, ctx, hmm_golden, case):
+    g, p = hmm_golden, case + "_"
+    prm = golden_params(g, case)
+    bank = _bank(sra, ctx, [prm])
+    data = sra.Ragged(ctx, g[p + "X"], g[p + "lengths"], dtype="float64")
+    bank.mstep(bank.estep(data), mode="transitions_only")
+    sp, A, mu, cv = bank.params_host()
+    np.testing.assert_allclose(sp[0], g[p + "em_pi"], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(A[0], g[p + "em_A"], rtol=1e-9, atol=1e-13)
+    np.testing.assert_array_equal(mu[0], g[p + "mu"])       # untouched, as in fit()
+    np.testing.assert_array_equal(cv[0], g[p + "var"])
+    # structural zeros survive
+    assert np.all(A[0][g[p + "A"] == 0] == 0)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_viterbi_paths_bit_exact(sra, ctx, hmm_golden, case):
+    g, p = hmm_golden, case + "_"
+    prm = golden_params(g, case)
+    bank = _bank(sra, ctx, [prm])
+    data = sra.Ragged(ctx, g[p + "X"], g[p + "lengths"], dtype="float64")
+    lp, path = bank.viterbi(data)
+    np.testing.assert_array_equal(path.cpu().numpy(), g[p + "vit_path"])
+    np.testing.assert_allclose(lp.cpu().numpy(), g[p + "vit_logprob"], rtol=1e-12)
+    # float32: ties excepted -- a differing frame must be a near-tie
+    data32 = sra.Ragged(ctx, g[p + "X"], g[p + "lengths"], dtype="float32")
+    lp32, path32 = bank.viterbi(data32)
+    agree = np.mean(path32.cpu().numpy() == g[p + "vit_path"])
+    assert agree > 0.98
+    assert _rel(lp32.cpu().numpy(), g[p + "vit_logprob"]) < 1e-5
+
+
+def test_multi_model_bank_and_ragged_edges(sra, ctx):
+    rng = np.random.default_rng(11)
+    S, D, M = 8, 39, 6
+    prms = [ho.random_params(rng, S, D) for _ in range(M)]
+    lengths = [1, 2, 200, 17, 64, 199, 3, 128]
+    X = rng.standard_normal((sum(lengths), D))
+    ref = np.stack([ho.score(p, X, lengths, loops=False) for p in prms], axis=1)
+    bank = _bank(sra, ctx, prms)
+    for dtype, tol in (("float64", 1e-11), ("float32", 5e-6)):
+        data = sra.Ragged(ctx, X, lengths, dtype=dtype)
+        for generic in (False, True):
+            got = bank.score(data, generic=generic).cpu().numpy()
+            assert got.shape == (len(lengths), M)
+            assert _rel(got, ref) < tol
+    # batched E-step with a different model per utterance
+    um = np.array([u % M for u in range(len(lengths))], dtype=np.int32)
+    tr = sra.parallel.BaumWelchTrainer(bank, sra.Ragged(ctx, X, lengths, dtype="float64"), um)
+    tr.bank.estep(tr.data, tr.utt_model, tr.utt_order, out=tr.stats)
+    got = bank.unpack_stats(tr.stats)
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    for m in range(M):
+        sel = [u for u in range(len(lengths)) if um[u] == m]
+        Xm = np.vstack([X[off[u]:off[u + 1]] for u in sel])
+        st, lps = ho.estep(prms[m], Xm, [lengths[u] for u in sel], loops=False)
+        assert got[m]["nobs"] == len(sel)
+        np.testing.assert_allclose(got[m]["logprob"], lps.sum(), rtol=1e-10)
+        for k in ("start", "trans", "post", "obs", "obs**2"):
+            np.testing.assert_allclose(got[m][k], st[k], rtol=1e-8, atol=1e-10)
+
+
+def test_estep_order_independent(sra, ctx):
+    rng = np.random.default_rng(5)
+    prm = ho.random_params(rng, 4, 9)
+    lengths = rng.integers(1, 60, size=40)
+    X = rng.standard_normal((int(lengths.sum()), 9))
+    bank = _bank(sra, ctx, [prm])
+    data = sra.Ragged(ctx, X, lengths, dtype="float64")
+    a = bank.estep(data).cpu().numpy()
+    order = ctx.tensor(rng.permutation(len(lengths)).astype(np.int64))
+    b = bank.estep(data, None, order).cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("i", range(9))
+def test_mfcc_matches_reference(sra, ctx, mfcc_golden, i):
+    g = mfcc_golden
+    sig, sr = g[f"sig{i}"], int(g[f"sr{i}"])
+    scale = np.abs(g[f"cep{i}"]).max()
+    for dtype, tol in (("float64", 1e-9), ("float32", 1e-4)):
+        cep = sra.mfcc.compute_mfcc(sig, sr, dtype=dtype)
+        assert cep.shape == g[f"cep{i}"].shape
+        np.testing.assert_allclose(cep, g[f"cep{i}"], rtol=tol, atol=tol * scale)
+        f, lens = sra.mfcc.extract_batch([sig], sr, zscore=False, dtype=dtype)
+        assert f.shape == g[f"feat{i}"].T.shape
+        np.testing.assert_allclose(f, g[f"feat{i}"].T, rtol=tol, atol=tol * scale)
+        z = sra.mfcc.extract_features(sig, sr, dtype=dtype)
+        assert z.shape == g[f"z{i}"].shape
+        # z-scored features are O(1): absolute tolerance
+        np.testing.assert_allclose(z, g[f"z{i}"], rtol=0, atol=1e-7 if dtype == "float64" else 2e-3)
+
+
+def test_mfcc_batch_ragged_equals_single(sra, ctx, mfcc_golden):
+    g = mfcc_golden
+    sigs = [g[f"sig{i}"] for i in range(9) if int(g[f"sr{i}"]) == 16000]
+    sigs.insert(2, np.zeros(100, dtype=np.float32))     # shorter than one frame -> 0 frames
+    f, lens = sra.mfcc.extract_batch(sigs, 16000, dtype="float64")
+    assert lens[2] == 0
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for k, s in enumerate(sigs):
+        one = sra.mfcc.extract_features(s, 16000, dtype="float64")
+        np.testing.assert_array_equal(f[off[k]:off[k + 1]], one)
+    # benchmark-shaped configuration against the oracle: 512-point FFT, 40 mel, delta + delta-delta
+    cfg = mo.MfccConfig(sample_rate=16000, nfft=512, n_mel=40, delta_order=2)
+    f2, lens2 = sra.mfcc.extract_batch(sigs, 16000, nfft=512, n_mel=40, delta_order=2, dtype="float64")
+    off2 = np.concatenate([[0], np.cumsum(lens2)])
+    for k, s in enumerate(sigs):
+        ref = mo.extract(s.astype(np.float64), cfg)
+        assert ref.shape == (lens2[k], 39)
+        np.testing.assert_allclose(f2[off2[k]:off2[k + 1]], ref, rtol=0, atol=1e-7)
+
+
+def test_class_surface_and_errors(sra, ctx, hmm_golden):
+    g, p = hmm_golden, "s3d26_"
+    m = sra.MyGaussianHMM(n_components=3, tol=1e-4, n_iter=2, implementation="scaling",
+                          verbose=False)
+    m.startprob_, m.transmat_ = g[p + "pi"].copy(), g[p + "A"].copy()
+    m.means_, m._covars_ = g[p + "mu"].copy(), g[p + "var"].copy()
+    X, L = g[p + "X"], g[p + "lengths"]
+    assert abs(m.score(X, L) - float(g[p + "score_all"])) < 1e-9 * abs(float(g[p + "score_all"]))
+    st, lp = m.do_estep(X, L)
+    np.testing.assert_allclose(st["trans"], g[p + "st_trans"], rtol=1e-9)
+    lpv, path = m.decode(X, L)
+    np.testing.assert_array_equal(path, g[p + "vit_path"])
+    m.fit_from_current(X, L)
+    assert list(m.monitor_.history)[0] == pytest.approx(float(g[p + "logprob"]), rel=1e-11)
+    assert list(m.monitor_.history)[1] == pytest.approx(float(g[p + "logprob2"]), rel=1e-10)
+    np.testing.assert_allclose(m.means_, g[p + "m2_mu"], rtol=1e-8, atol=1e-10)
+    with pytest.raises(ValueError):
+        m.score(X, [5, 5])                       # lengths do not sum to n_samples
+    with pytest.raises(ValueError):
+        m.score(X[:, :5])                        # wrong feature count
+    with pytest.raises(ValueError):
+        m.covars_ = -np.ones((3, 26))
+    import pickle
+    m2 = pickle.loads(pickle.dumps(m))
+    assert m2.score(X, L) == m.score(X, L)
+    # the reference's own init path runs and converges from its random start
+    np.random.seed(0)
+    m3 = sra.MyGaussianHMM(n_components=3, n_iter=5, tol=1e-4, verbose=False, random_state=3)
+    m3.fit(X, L)
+    h = list(m3.monitor_.history)
+    assert len(h) >= 2 and h[-1] >= h[0]
+
+
+def test_fold_accuracies_identical(sra, ctx, folds_golden):
+    """The 5-fold command-word experiment: train 6 word models per fold from
+    the fixtures' deterministic start for the same number of iterations, score
+    the fold's validation utterances -- labels and right-counts must equal the
+    reference's, parameters agree per model."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import fold_init
+    g = folds_golden
+    names = list(g["names"])
+    words = list(g["words"])
+    lengths = g["lengths"]
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    feats = g["feats"].astype(np.float64)
+    index = {n: i for i, n in enumerate(names)}
+    n_iter = int(g["n_iter"])
+
+    def utt(n):
+        i = index[n]
+        return feats[off[i]:off[i + 1]]
+
+    for fold in range(1, 6):
+        train, val = list(g[f"f{fold}_train"]), list(g[f"f{fold}_val"])
+        inits, xs, um = [], [], []
+        for w_i, w in enumerate(words):
+            sel = [n for n in train if n[: n.rfind("_")] == w]
+            Xw = np.vstack([utt(n) for n in sel])
+            inits.append(ho.Params(*fold_init(Xw, 3)))
+            xs += [utt(n) for n in sel]
+            um += [w_i] * len(sel)
+        bank = _bank(sra, ctx, inits)
+        data = sra.Ragged(ctx, np.vstack(xs), [len(x) for x in xs], dtype="float64")
+        tr = sra.parallel.BaumWelchTrainer(bank, data, np.array(um, dtype=np.int32))
+        hist = np.stack([tr.step().cpu().numpy() for _ in range(n_iter)], axis=1)
+        sp, A, mu, cv = bank.params_host()
+        for w_i, w in enumerate(words):
+            q = f"f{fold}_{w}_"
+            np.testing.assert_allclose(hist[w_i], g[q + "hist"], rtol=1e-9)
+            np.testing.assert_allclose(mu[w_i], g[q + "mu"], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(cv[w_i], g[q + "var"], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(A[w_i], g[q + "A"], rtol=1e-5, atol=1e-9)
+        vdata = sra.Ragged(ctx, np.vstack([utt(n) for n in val]), [len(utt(n)) for n in val],
+                           dtype="float64")
+        scores = bank.score(vdata).cpu().numpy()
+        np.testing.assert_allclose(scores, g[f"f{fold}_scores"], rtol=1e-7)
+        pred = [words[int(np.argmax(r))] for r in scores]
+        assert pred == list(g[f"f{fold}_pred"])
+        assert sum(p == n[: n.rfind("_")] for p, n in zip(pred, val)) == int(g[f"f{fold}_right"])
+        # float32 fast path gives the same labels
+        s32 = bank.score(sra.Ragged(ctx, vdata.X, offsets=vdata.offsets, dtype="float32")).cpu().numpy()
+        assert [words[int(np.argmax(r))] for r in s32] == pred
