@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""Headline benchmark: batched HMM scoring, 65,536 synthetic utterances x 200
+frames x 39-dim features against 6 word models of 8 states (configs[1] of
+BASELINE.json), on N GPUs of one node (utterances sharded, no collective).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one pass of srx_forward_score over the rank's batch, inputs resident
+in HBM.  Rank 0 prints ONE JSON line.  Beside the headline it carries
+  roofline      algorithmic HBM bytes (156 B/frame in + 48 B/utterance out)
+                / event-timed duration of the scoring launch, against 8 TB/s
+  cpu_baseline  the loop-faithful fp64 CPU oracle on a bounded sample
+  extra         front-end frames/s (16 kHz, 512-pt FFT, 40 mel, 39-dim) and
+                Baum-Welch iterations/s (6 models x 16 states), each with its
+                own size, measured outside the timed region of the headline.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec
+N_UTTS, T_FRAMES, N_FEAT = 65536, 200, 39
+N_MODELS, N_STATES = 6, 8
+
+
+def synth_models(rng, M, S, D):
+    return (rng.dirichlet(np.ones(S), size=M), rng.dirichlet(np.ones(S), size=(M, S)),
+            rng.standard_normal((M, S, D)), rng.uniform(0.5, 1.5, (M, S, D)))
+
+
+def cpu_baseline(sample_utts, seed=1234):
+    """Loop-faithful CPU oracle (same per-frame / per-state Python loops as
+    my_hmmlearn/utils.py:132-150) on `sample_utts` utterances, one core."""
+    from oracle import hmm_oracle as ho
+    rng = np.random.default_rng(seed)
+    sp, A, mu, cv = synth_models(np.random.default_rng(7), N_MODELS, N_STATES, N_FEAT)
+    X = rng.standard_normal((sample_utts * T_FRAMES, N_FEAT))
+    lengths = [T_FRAMES] * sample_utts
+    t0 = time.perf_counter()
+    for m in range(N_MODELS):
+        ho.score(ho.Params(sp[m], A[m], mu[m], cv[m]), X, lengths, loops=True)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for m in range(N_MODELS):
+        ho.score(ho.Params(sp[m], A[m], mu[m], cv[m]), X, lengths, loops=False)
+    dtv = time.perf_counter() - t1
+    return {"value": sample_utts * T_FRAMES / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{sample_utts} utterances x {T_FRAMES} frames x {N_FEAT} dims, 6 models x 8 "
+                      f"states, fp64 Python loops as in the reference ({dt:.1f} s)",
+            "vectorised_numpy_frames_per_s": sample_utts * T_FRAMES / dtv}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--utts", type=int, default=N_UTTS, help="utterances per GPU (default = config)")
+    ap.add_argument("--cpu-sample", type=int, default=96)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--train-utts", type=int, default=131072,
+                    help="utterances per GPU for the Baum-Welch extra (config: 1M total)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import speech_recognition_amd as sra
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    ctx = sra.Context.default(local)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---------------------------------------------------------------- workload
+    U = args.utts
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    X = torch.randn((U * T_FRAMES, N_FEAT), device=dev, dtype=torch.float32, generator=gen)
+    offsets = torch.arange(0, (U + 1) * T_FRAMES, T_FRAMES, device=dev, dtype=torch.int64)
+    data = sra.Ragged(ctx, X, offsets=offsets, dtype="float32")
+    sp, A, mu, cv = synth_models(np.random.default_rng(7), N_MODELS, N_STATES, N_FEAT)
+    bank = sra.HMMBank(ctx, sp, A, mu, cv)
+    scores = torch.empty((U, N_MODELS), dtype=torch.float64, device=dev)
+
+    for _ in range(args.warmup):
+        bank.score(data, out=scores)
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        bank.score(data, out=scores)
+        ev[k][1].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    checksum = float(scores.sum().item())
+    assert np.isfinite(checksum), "scores are not finite"
+
+    frames_per_step = U * T_FRAMES * world
+    value = frames_per_step * args.steps / dt
+    alg_bytes = U * T_FRAMES * N_FEAT * 4 + U * N_MODELS * 8      # per launch, per GPU
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("score_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "hmm_scored_frames_per_sec_6_models", "value": value, "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "batched scoring: 65,536 utterances x 200 frames x 39-dim vs 6 HMMs "
+                               "x 8 states (diag Gaussians)",
+                   "utterances_per_gpu": U, "frames_per_utterance": T_FRAMES,
+                   "n_features": N_FEAT, "n_models": N_MODELS, "n_states": N_STATES,
+                   "parallelism": f"utterances sharded over {world} GPU(s), no collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        "checksum": checksum,
+    }
+
+    # ------------------------------------------------------------------ extras
+    if not args.no_extra:
+        extra = {}
+        del X, data
+        torch.cuda.empty_cache()
+        # front-end: 16 kHz, 25/10 ms, 512-pt FFT, 40 mel, 13 ceps + delta + delta-delta
+        n_utt_fe, n_samp = 8192, 48000                      # 3 s pseudo-utterances
+        g2 = torch.Generator(device=dev)
+        g2.manual_seed(99 + rank)
+        audio = 0.2 * torch.randn((n_utt_fe * n_samp,), device=dev, dtype=torch.float32, generator=g2)
+        so = np.arange(0, (n_utt_fe + 1) * n_samp, n_samp, dtype=np.int64)
+        plan = sra.MfccPlan(ctx, 16000, nfft=512, n_mel=40, delta_order=2, zscore=True)
+        feats, fo = plan.run(audio, so)
+        barrier()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            plan.run(audio, so, out=feats)
+        barrier()
+        dtf = (time.perf_counter() - t0) / reps
+        raw_frames = n_utt_fe * ((n_samp - 400) // 160 + 1)
+        extra["mfcc"] = {"frames_per_s": raw_frames * world / dtf, "frames_per_gpu": raw_frames,
+                         "ms": dtf * 1e3,
+                         "hbm_frac": raw_frames * 796 / dtf / 1e9 / HBM_PEAK_GBS,
+                         "config": "16 kHz, 400/160 samples, 512-pt FFT, 40 mel, 13 MFCC+d+dd, z-score"}
+        del audio, feats
+        torch.cuda.empty_cache()
+        # Baum-Welch: 6 models x 16 states, utterance u trains model u mod 6
+        Ut = args.train_utts
+        g3 = torch.Generator(device=dev)
+        g3.manual_seed(4321 + rank)
+        Xt = torch.randn((Ut * T_FRAMES, N_FEAT), device=dev, dtype=torch.float32, generator=g3)
+        offt = torch.arange(0, (Ut + 1) * T_FRAMES, T_FRAMES, device=dev, dtype=torch.int64)
+        dt_ = sra.Ragged(ctx, Xt, offsets=offt, dtype="float32")
+        sp2, A2, mu2, cv2 = synth_models(np.random.default_rng(8), N_MODELS, 16, N_FEAT)
+        bank2 = sra.HMMBank(ctx, sp2, A2, mu2, cv2)
+        tr = sra.parallel.BaumWelchTrainer(bank2, dt_, np.arange(Ut) % N_MODELS)
+        tr.step()
+        barrier()
+        t0 = time.perf_counter()
+        iters = 3
+        for _ in range(iters):
+            lp = tr.step()
+        barrier()
+        dtt = (time.perf_counter() - t0) / iters
+        extra["baum_welch"] = {"iter_per_s": 1.0 / dtt, "ms_per_iter": dtt * 1e3,
+                               "utterances_total": Ut * world, "frames_per_s": Ut * world * T_FRAMES / dtt,
+                               "config": "6 models x 16 states x 39 dims, full M-step, stats all-reduce",
+                               "logprob_model0": float(lp[0].item())}
+        out["extra"] = extra
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
