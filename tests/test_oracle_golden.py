@@ -96,3 +96,39 @@ def test_split_lengths_error():
         ho.split_lengths(np.zeros((5, 2)), [2, 2])
     with pytest.raises(ValueError):
         ho.forward_scaling_loops(np.ones(2) / 2, np.ones((3, 3)) / 3, np.ones((4, 3)))
+
+
+# ---- compiled C oracle (oracle/srx_oracle.c) pinned to the same vectors ------
+from oracle import c_oracle as co
+
+needs_c = pytest.mark.skipif(not co.available(), reason="run `make -C oracle` first")
+
+
+@needs_c
+@pytest.mark.parametrize("case", CASES)
+def test_c_oracle_matches_reference(hmm_golden, case):
+    g, p = hmm_golden, case + "_"
+    prm = golden_params(g, case)
+    X, L = g[p + "X"], g[p + "lengths"]
+    np.testing.assert_allclose(co.score(prm, X, L), g[p + "utt_logprob"], rtol=1e-12)
+    rec = co.estep(prm, X, L)
+    S, D = prm.S, prm.D
+    assert rec[0] == int(g[p + "st_nobs"])
+    np.testing.assert_allclose(rec[1], g[p + "logprob"], rtol=1e-12)
+    o = 2
+    for n, size in (("start", S), ("trans", S * S), ("post", S), ("obs", S * D), ("obs2", S * D)):
+        np.testing.assert_allclose(rec[o:o + size], g[p + "st_" + n].ravel(), rtol=1e-10, atol=1e-12)
+        o += size
+    lp, path = co.viterbi(prm, X, L)
+    np.testing.assert_allclose(lp, g[p + "vit_logprob"], rtol=1e-13)
+    np.testing.assert_array_equal(path, g[p + "vit_path"])
+
+
+@needs_c
+@pytest.mark.parametrize("i", range(9))
+def test_c_oracle_cepstra_match_reference(mfcc_golden, i):
+    g = mfcc_golden
+    sig, sr = g[f"sig{i}"].astype(np.float64), int(g[f"sr{i}"])
+    cfg = _cfg(sr)
+    cep = co.cepstra(sig, cfg, g["fbank1024"])
+    np.testing.assert_allclose(cep, g[f"cep{i}"], rtol=1e-9, atol=1e-8)
