@@ -160,6 +160,12 @@ int srx_estep_stats(srx_handle_t h, const void* X, int dtype, const int64_t* utt
                     const int64_t* utt_order, const srx_models_t* models, double* out_stats,
                     void* stream);
 
+/* Same contract, always through the shape-generic kernels. */
+int srx_estep_stats_generic(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
+                            int64_t n_utts, int64_t n_frames, const int32_t* utt_model,
+                            const int64_t* utt_order, const srx_models_t* models,
+                            double* out_stats, void* stream);
+
 /* ---- M-step: do_em_mstep (hmm.py:435-451) and do_mstep (hmm.py:165-184),
  * applied in place to every model of the bank from its statistics record. */
 int srx_mstep(srx_handle_t h, const double* stats, const srx_priors_t* priors, int mode,

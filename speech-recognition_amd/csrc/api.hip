@@ -170,17 +170,38 @@ int srx_viterbi(srx_handle_t h, const void* X, int dtype, const int64_t* utt_off
                                out_path, out_logprob, (hipStream_t)stream);
 }
 
+static int estep_common(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
+                        int64_t n_utts, int64_t n_frames, const int32_t* utt_model,
+                        const int64_t* utt_order, const srx_models_t* models, double* out_stats,
+                        void* stream, bool allow_fused, const char* who) {
+    int rc = check_common(h, X, dtype, n_utts, n_frames, utt_offsets, who);
+    if (rc) return rc;
+    if ((rc = check_models(models, who))) return rc;
+    SRX_REQUIRE(out_stats != nullptr, "%s: NULL out_stats", who);
+    SRX_HIP(hipSetDevice(h->device));
+    if (allow_fused && dtype == SRX_F32) {
+        rc = srx_fused_estep(h, X, utt_offsets, n_utts, n_frames, utt_model, utt_order, models,
+                             out_stats, (hipStream_t)stream);
+        if (rc != SRX_EUNSUPPORTED) return rc;
+    }
+    return srx_generic_estep(h, X, dtype, utt_offsets, n_utts, n_frames, utt_model, utt_order,
+                             models, out_stats, (hipStream_t)stream);
+}
+
 int srx_estep_stats(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
                     int64_t n_utts, int64_t n_frames, const int32_t* utt_model,
                     const int64_t* utt_order, const srx_models_t* models, double* out_stats,
                     void* stream) {
-    int rc = check_common(h, X, dtype, n_utts, n_frames, utt_offsets, "srx_estep_stats");
-    if (rc) return rc;
-    if ((rc = check_models(models, "srx_estep_stats"))) return rc;
-    SRX_REQUIRE(out_stats != nullptr, "srx_estep_stats: NULL out_stats");
-    SRX_HIP(hipSetDevice(h->device));
-    return srx_generic_estep(h, X, dtype, utt_offsets, n_utts, n_frames, utt_model, utt_order,
-                             models, out_stats, (hipStream_t)stream);
+    return estep_common(h, X, dtype, utt_offsets, n_utts, n_frames, utt_model, utt_order, models,
+                        out_stats, stream, true, "srx_estep_stats");
+}
+
+int srx_estep_stats_generic(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
+                            int64_t n_utts, int64_t n_frames, const int32_t* utt_model,
+                            const int64_t* utt_order, const srx_models_t* models,
+                            double* out_stats, void* stream) {
+    return estep_common(h, X, dtype, utt_offsets, n_utts, n_frames, utt_model, utt_order, models,
+                        out_stats, stream, false, "srx_estep_stats_generic");
 }
 
 int srx_mstep(srx_handle_t h, const double* stats, const srx_priors_t* priors, int mode,

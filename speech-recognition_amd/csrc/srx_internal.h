@@ -99,3 +99,8 @@ int srx_generic_mstep(srx_context* h, const double* stats, const srx_priors_t* p
 int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
                    int64_t n_frames, const srx_models_t* models, double* out,
                    hipStream_t st);
+
+// Implemented in estep_fused.hip (float32, S <= 16, D <= 40), else SRX_EUNSUPPORTED.
+int srx_fused_estep(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
+                    const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* models,
+                    double* out_stats, hipStream_t st);

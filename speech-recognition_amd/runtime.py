@@ -202,12 +202,13 @@ class HMMBank:
                               self.ctx.stream_ptr()), "srx_viterbi")
         return lp, path
 
-    def estep(self, data, utt_model=None, utt_order=None, out=None):
+    def estep(self, data, utt_model=None, utt_order=None, out=None, generic=False):
         """Packed statistics (M, stats_size) float64 on the device."""
         self._check(data)
         if out is None:
             out = torch.empty((self.M, self.stats_size), dtype=torch.float64, device=self.ctx.device)
-        check(lib.srx_estep_stats(self.ctx.handle, ptr(data.X), data.code, ptr(data.offsets), data.U,
+        fn = lib.srx_estep_stats_generic if generic else lib.srx_estep_stats
+        check(fn(self.ctx.handle, ptr(data.X), data.code, ptr(data.offsets), data.U,
                                   data.n_frames, ptr(utt_model), ptr(utt_order),
                                   C.byref(self._struct), ptr(out), self.ctx.stream_ptr()),
               "srx_estep_stats")

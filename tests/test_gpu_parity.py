@@ -54,13 +54,15 @@ def test_emission_and_score_match_reference(sra, ctx, hmm_golden, case, dtype, t
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("dtype", ["float64", "float32"])
-def test_estep_and_mstep_match_reference(sra, ctx, hmm_golden, case, dtype):
+@pytest.mark.parametrize("dtype,generic", [("float64", False), ("float32", False), ("float32", True)])
+def test_estep_and_mstep_match_reference(sra, ctx, hmm_golden, case, dtype, generic):
+    """float32 + generic=False is the fused matrix-core E-step, the other two
+    go through the shape-generic kernels."""
     g, p = hmm_golden, case + "_"
     prm = golden_params(g, case)
     bank = _bank(sra, ctx, [prm])
     data = sra.Ragged(ctx, g[p + "X"], g[p + "lengths"], dtype=dtype)
-    stats = bank.estep(data)
+    stats = bank.estep(data, generic=generic)
     st = bank.unpack_stats(stats)[0]
     rt = 1e-9 if dtype == "float64" else 2e-5
     assert st["nobs"] == int(g[p + "st_nobs"])
@@ -78,7 +80,7 @@ def test_estep_and_mstep_match_reference(sra, ctx, hmm_golden, case, dtype):
     np.testing.assert_allclose(mu[0], g[p + "m_mu"], rtol=pt, atol=pt)
     np.testing.assert_allclose(cv[0], g[p + "m_var"], rtol=pt, atol=pt)
     # second iteration from the re-estimated model
-    stats2 = bank.estep(data)
+    stats2 = bank.estep(data, generic=generic)
     lp2 = float(stats2[0, 1].item())
     assert abs(lp2 - float(g[p + "logprob2"])) < (1e-9 if dtype == "float64" else 1e-5) * abs(lp2)
     bank.mstep(stats2, mode="full")
@@ -148,6 +150,20 @@ def test_multi_model_bank_and_ragged_edges(sra, ctx):
         np.testing.assert_allclose(got[m]["logprob"], lps.sum(), rtol=1e-10)
         for k in ("start", "trans", "post", "obs", "obs**2"):
             np.testing.assert_allclose(got[m][k], st[k], rtol=1e-8, atol=1e-10)
+    # the same batch through the fused float32 E-step, in label order and unsorted
+    d32 = sra.Ragged(ctx, X, lengths, dtype="float32")
+    umd = ctx.tensor(um)
+    for order in (tr.utt_order, None):
+        got32 = bank.unpack_stats(bank.estep(d32, umd, order))
+        for m in range(M):
+            sel = [u for u in range(len(lengths)) if um[u] == m]
+            Xm = np.vstack([X[off[u]:off[u + 1]] for u in sel])
+            st, lps = ho.estep(prms[m], Xm, [lengths[u] for u in sel], loops=False)
+            assert got32[m]["nobs"] == len(sel)
+            np.testing.assert_allclose(got32[m]["logprob"], lps.sum(), rtol=1e-5)
+            for k in ("start", "trans", "post", "obs", "obs**2"):
+                np.testing.assert_allclose(got32[m][k], st[k], rtol=2e-5,
+                                           atol=2e-5 * max(1.0, np.abs(st[k]).max()))
 
 
 def test_estep_order_independent(sra, ctx):
