@@ -96,6 +96,12 @@ const char* srx_last_error(void);
 /* One context per GPU / rank; owns the scratch workspace the kernels need. */
 int srx_create(int device, srx_handle_t* out);
 int srx_destroy(srx_handle_t h);
+/* Context options.  SRX_OPT_EXACT_F32 = 1 keeps the SRX_F32 scoring path on
+ * exact-f32 matrix instructions; the default (0) evaluates the emission
+ * contraction with split-bf16 operands (three partial products, error ~1e-6
+ * relative on a log-likelihood), which is several times faster. */
+enum srx_option { SRX_OPT_EXACT_F32 = 1 };
+int srx_set_option(srx_handle_t h, int option, int value);
 /* Bytes of scratch currently held by the context (diagnostics). */
 int64_t srx_workspace_bytes(srx_handle_t h);
 

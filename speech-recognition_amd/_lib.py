@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libsrx.so")
 
 SRX_F32, SRX_F64 = 0, 1
 SRX_MSTEP_FULL, SRX_MSTEP_TRANSITIONS_ONLY = 0, 1
+SRX_OPT_EXACT_F32 = 1
 SRX_EINVAL, SRX_EHIP, SRX_ENOMEM, SRX_EUNSUPPORTED = -1, -2, -3, -4
 
 
@@ -50,6 +51,7 @@ SIGNATURES = {
     "srx_last_error": (C.c_char_p, []),
     "srx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "srx_destroy": (C.c_int, [_vp]),
+    "srx_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
     "srx_workspace_bytes": (_i64, [_vp]),
     "srx_stats_size": (_i64, [_i32, _i32]),
     "srx_mfcc_plan_create": (C.c_int, [_vp, C.POINTER(MfccCfg), C.POINTER(_vp)]),

@@ -102,6 +102,14 @@ int srx_destroy(srx_handle_t h) {
     return SRX_OK;
 }
 
+int srx_set_option(srx_handle_t h, int option, int value) {
+    SRX_REQUIRE(h != nullptr, "srx_set_option: NULL context");
+    switch (option) {
+        case SRX_OPT_EXACT_F32: h->exact_f32 = value != 0; return SRX_OK;
+        default: srx_set_error("srx_set_option: unknown option %d", option); return SRX_EINVAL;
+    }
+}
+
 int64_t srx_workspace_bytes(srx_handle_t h) {
     if (!h) return 0;
     int64_t s = 0;

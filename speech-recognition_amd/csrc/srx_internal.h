@@ -23,6 +23,7 @@ enum srx_ws_slot {
 struct srx_context {
     int device;
     int n_cu;
+    int exact_f32;   // SRX_OPT_EXACT_F32: keep the float32 paths on exact-f32 matrix instructions
     void* ws[WS_NUM];
     size_t ws_bytes[WS_NUM];
 };

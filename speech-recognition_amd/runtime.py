@@ -62,6 +62,11 @@ class Context:
     def stream_ptr(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def set_exact_f32(self, on):
+        """True: float32 scoring stays on exact-f32 matrix instructions; False
+        (default): split-bf16 emission contraction."""
+        check(lib.srx_set_option(self._h, _lib.SRX_OPT_EXACT_F32, int(bool(on))), "srx_set_option")
+
     def workspace_bytes(self):
         return int(lib.srx_workspace_bytes(self._h))
 
