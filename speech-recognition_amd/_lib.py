@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrx.so")
+LIB_PATH = os.environ.get("SRX_LIB") or os.path.join(_HERE, "libsrx.so")
 
 SRX_F32, SRX_F64 = 0, 1
 SRX_MSTEP_FULL, SRX_MSTEP_TRANSITIONS_ONLY = 0, 1

@@ -32,6 +32,7 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True):
+    extra = os.environ.get("SRX_CXXFLAGS", "").split()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(ROOT, "include", "srx.h"))
     objs = []
@@ -42,7 +43,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [_hipcc()] + FLAGS + extra + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd)))

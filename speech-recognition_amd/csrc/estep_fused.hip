@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o, 64));
 
-            const float* xbase = X + f0 * D + 2 * g;
+            const float* xbase = X + f0 * D;
             float* latp = lat + f0 * 16 + 4 * g;
             float* scp = scale + f0;
             float xc[R][2], xn[R][2];
@@ -210,9 +210,10 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                 const float* p = xbase + (int64_t)tc * D;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const int d0 = 8 * r + 2 * g;
-                    dst[r][0] = d0 < D ? p[8 * r] : 0.f;
-                    dst[r][1] = d0 + 1 < D ? p[8 * r + 1] : 0.f;
+                    // features past D meet zero weights: read a valid neighbour
+                    // instead of predicating the load
+                    dst[r][0] = p[min(8 * r + 2 * g, D - 1)];
+                    dst[r][1] = p[min(8 * r + 2 * g + 1, D - 1)];
                 }
             };
             auto emission = [&](const float (&x)[R][2]) {

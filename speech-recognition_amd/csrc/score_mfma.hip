@@ -23,6 +23,12 @@
 #include "srx_internal.h"
 
 #include <math.h>
+#include <stdlib.h>
+#include <type_traits>
+
+#ifndef SRX_ABL
+#define SRX_ABL 0
+#endif
 
 namespace {
 
@@ -77,6 +83,21 @@ __global__ void mfma_prep_kernel(srx_models_t md, int SP, int NT, int R, float* 
 }
 
 __device__ __forceinline__ float xchg16(float v) { return __shfl_xor(v, 16, 64); }
+
+// max / sum of a value with its partner 16 lanes away (lanes l and l^16), in
+// both lanes, without touching LDS: v_permlane16_swap exchanges the odd
+// 16-lane rows of one operand with the even rows of the other, so after
+// swapping two copies of v the pair (a, b) holds {v[l], v[l^16]} in some order.
+__device__ __forceinline__ float pair_max(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float pair_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 template <int SP, int NT, int R>
 __global__ __launch_bounds__(256, 2) void score_mfma_kernel(
@@ -140,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(
     }
 
     // ---- frame loads: two adjacent floats per r
-    const float* xbase = X + f0 * D + 2 * g;
+    const float* xbase = X + f0 * D;
     float xc[R][2], xn[R][2];
     auto load = [&](int t, float (&dst)[R][2]) {
         int tc = t < T ? t : T - 1;
@@ -148,9 +169,10 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(
         const float* p = xbase + (int64_t)tc * D;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int d0 = 8 * r + 2 * g;
-            dst[r][0] = d0 < D ? p[8 * r] : 0.f;
-            dst[r][1] = d0 + 1 < D ? p[8 * r + 1] : 0.f;
+            // features past D meet zero weights: read a valid neighbour instead of
+            // predicating the load (a predicated load costs a branch and a full wait)
+            dst[r][0] = p[min(8 * r + 2 * g, D - 1)];
+            dst[r][1] = p[min(8 * r + 2 * g + 1, D - 1)];
         }
     };
     if (Tmax > 0) load(0, xc);
@@ -242,21 +264,29 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(
 // hi(x) is the truncated upper 16 bits (exact remainder), lo is rounded.  The
 // relative error per product is <= ~3e-5 and averages out over the 2D terms;
 // scores agree with the exact-f32 kernel to ~1e-6 relative.
-// k-steps (8 bf16 per lane, the same order in the weight operand):
-//   HL(r)    [x0h x1h s0h s1h | x0l x1l s0l s1l] . [wh.. | wh..]   r = 0..R-1
-//   WL(r,r') [x0h x1h s0h s1h (r) | same (r')]   . [wl(r) | wl(r')]
-// with x0,x1 the lane's two features of block r and s = x^2 (formed in f32).
-// The 8x8 / 4x4 transition products also go to the matrix core (exact f32
-// 16x16x4, block-diagonal per tile): accumulator register q of lane group g is
-// tile row 4g+q, which is the k index that group supplies in k-step q, so
-// alpha feeds the next step without lane movement; only the per-model max and
-// sum cross lanes (one exchange each for 8 states, none for 4).
+//
+// Memory.  A lane reads 16 contiguous bytes per load: lane group g of
+// utterance u takes features 16q+4g .. 16q+4g+3 (q < RQ), so one wave
+// instruction moves 16 rows x 64 B instead of 16 x 32 B in 4-byte pieces (the
+// vector L1 handles a request per row segment, not per byte).  Loads are raw
+// buffer loads on a per-wave descriptor: rows are only 4-byte aligned and the
+// last features of a frame run into the next frame (they meet zero weights);
+// past the end of X the hardware range check returns zeros instead of
+// faulting.  A batch of 16 consecutive utterances must span < 4 GiB.
+//
+// k-steps per q (8 bf16 per lane, x = the lane's 4 features, s = x^2):
+//   [xh0..3 sh0..3] . wh     [xl0..3 sl0..3] . wh     [xh0..3 sh0..3] . wl
+// The transition products also go to the matrix core (exact f32 16x16x4,
+// block-diagonal per tile): accumulator register q of lane group g is tile
+// row 4g+q, which is the k index that group supplies in k-step q, so alpha
+// feeds the next step without lane movement; only the per-model max and sum
+// cross lanes (one v_permlane16_swap each for 8 states, none for 4).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct SplitTables {
-    const unsigned* Wp;   // [NT*16 rows][KS k-steps][4 lane groups][4 dwords] packed bf16 pairs
+    const unsigned* Wp;   // [NT*16 rows][RQ][2 (hi, lo)][4 lane groups][4 dwords] packed bf16 pairs
     const float* cst;     // [NT*16]
     const float* A;       // [M][S][S]
     const float* pi;      // [M][S]
@@ -268,36 +298,31 @@ __device__ __host__ inline unsigned bf16_rne(float f) {
     return u >> 16;
 }
 
-// One thread per (row, k-step, lane group): the 8 weights that face the 8
-// feature slots of that k-step.
-__global__ void split_prep_kernel(srx_models_t md, int SP, int NT, int R, unsigned* Wp, float* cst,
+// One thread per (row, q, part, lane group): the 8 weights facing the slots
+// [x0 x1 x2 x3 s0 s1 s2 s3] of features 16q+4g .. 16q+4g+3.
+__global__ void split_prep_kernel(srx_models_t md, int SP, int NT, int RQ, unsigned* Wp, float* cst,
                                   float* A, float* pi) {
     const int M = md.n_models, S = md.n_states, D = md.n_features;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nth = gridDim.x * blockDim.x;
-    const int KS = R + (R + 1) / 2;
-    for (int i = tid; i < NT * 16 * KS * 4; i += nth) {
-        const int g = i & 3, ks = (i >> 2) % KS, row = (i >> 2) / KS;
+    for (int i = tid; i < NT * 16 * RQ * 2 * 4; i += nth) {
+        const int g = i & 3, part = (i >> 2) & 1, q = (i >> 3) % RQ, row = (i >> 3) / RQ;
         const int m = row / SP, s = row % SP;
         unsigned short v[8];
         for (int j = 0; j < 8; ++j) {
-            int r, lo_part;
-            if (ks < R) { r = ks; lo_part = 0; }                        // HL: hi weights twice
-            else { r = 2 * (ks - R) + (j >> 2); lo_part = 1; }          // WL: lo weights of r, r'
-            const int e = j & 3;                                        // x0 x1 s0 s1
-            const int d = 8 * r + 2 * g + (e & 1);
+            const int d = 16 * q + 4 * g + (j & 3);
             float wv = 0.f;
-            if (m < M && s < S && r < R && d < D) {
+            if (m < M && s < S && d < D) {
                 const size_t k = ((size_t)m * S + s) * D + d;
                 const double var = fmax(md.covars[k], 2.2250738585072014e-308);
-                wv = (float)((e >> 1) ? (-0.5 / var) * 1.4426950408889634
+                wv = (float)((j >> 2) ? (-0.5 / var) * 1.4426950408889634
                                       : (md.means[k] / var) * 1.4426950408889634);
             }
             const unsigned hi = bf16_rne(wv);
             const float rem = wv - __builtin_bit_cast(float, hi << 16);
-            v[j] = (unsigned short)(lo_part ? bf16_rne(rem) : hi);
+            v[j] = (unsigned short)(part ? bf16_rne(rem) : hi);
         }
-        for (int q = 0; q < 4; ++q) Wp[(size_t)i * 4 + q] = (unsigned)v[2 * q] | ((unsigned)v[2 * q + 1] << 16);
+        for (int k = 0; k < 4; ++k) Wp[(size_t)i * 4 + k] = (unsigned)v[2 * k] | ((unsigned)v[2 * k + 1] << 16);
     }
     for (int row = tid; row < NT * 16; row += nth) {
         const int m = row / SP, s = row % SP;
@@ -317,32 +342,47 @@ __global__ void split_prep_kernel(srx_models_t md, int SP, int NT, int R, unsign
     for (int i = tid; i < M * S; i += nth) pi[i] = (float)md.startprob[i];
 }
 
-template <int SP, int NT, int R>
+template <int SP, int NT, int RQ>
 __global__ __launch_bounds__(256, 2) void score_split_kernel(
     const float* __restrict__ X, const int64_t* __restrict__ off, int64_t U, int64_t n_frames,
     int M, int S, int D, SplitTables tb, double* __restrict__ out) {
-    constexpr int RP = (R + 1) / 2;     // WL k-steps
-    constexpr int KS = R + RP;
     const int lane = threadIdx.x & 63, g = lane >> 4, ul = lane & 15;
     const int64_t group = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (group * 16 >= U) return;
     const int64_t u = group * 16 + ul;
     const bool valid = u < U;
     const int64_t uc = valid ? u : U - 1;
-    int64_t f0 = off[uc];
+    const int64_t f0 = off[uc];
     const int T = valid ? (int)(off[uc + 1] - f0) : 0;
-    if (f0 > n_frames - 1) f0 = n_frames - 1;
     int Tmax = T;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o, 64));
 
+    // ---- per-wave buffer descriptor over [first row of the batch, end of X)
+    const int64_t u_last = group * 16 + 15 < U - 1 ? group * 16 + 15 : U - 1;
+    const int64_t fbase = off[group * 16];
+    const int64_t span = (off[u_last + 1] - fbase) * D * 4;           // bytes, uniform
+    const int64_t rest = (n_frames - fbase) * (int64_t)D * 4;
+    const unsigned nrec = (unsigned)(rest < 0xFFFFFF00ll ? rest : 0xFFFFFF00ll);
+    const bool span_ok = span < 0xFFFFFF00ll;
+    const unsigned base_lo = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)(X + fbase * D)));
+    const unsigned base_hi = __builtin_amdgcn_readfirstlane((unsigned)(((uintptr_t)(X + fbase * D)) >> 32));
+    const float* xb = (const float*)(((uintptr_t)base_hi << 32) | base_lo);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)xb, 0, __builtin_amdgcn_readfirstlane(span_ok ? nrec : 0u), 0x00020000);
+    const unsigned row_off = (unsigned)((f0 - fbase) * D * 4) + 16u * g;   // this lane, frame 0, q = 0
+    const unsigned row_bytes = (unsigned)D * 4u;
+
     // ---- loop-invariant registers: packed weights, constants, transition operands
-    u32x4 w[NT][KS];
+    u32x4 wh[NT][RQ], wl[NT][RQ];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            w[nt][ks] = *(const u32x4*)(tb.Wp + ((((size_t)(nt * 16 + ul)) * KS + ks) * 4 + g) * 4);
+        for (int q = 0; q < RQ; ++q) {
+            const unsigned* p = tb.Wp + ((((size_t)(nt * 16 + ul)) * RQ + q) * 2 * 4 + g) * 4;
+            wh[nt][q] = *(const u32x4*)p;
+            wl[nt][q] = *(const u32x4*)(p + 16);
+        }
     f32x4 c0[NT];
     float atop[NT][4];
     int model[NT];
@@ -356,8 +396,8 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
             const int src = 4 * g + q, dst = ul;
             const int ms = (nt * 16 + src) / SP, md_ = (nt * 16 + dst) / SP;
             const int ss = src % SP, sd = dst % SP;
-            atop[nt][q] = (ms == md_ && ms < M && ss < S && sd < S)
-                              ? tb.A[((size_t)ms * S + ss) * S + sd] : 0.f;
+            const bool ok = ms == md_ && ms < M && ss < S && sd < S;
+            atop[nt][q] = tb.A[ok ? ((size_t)ms * S + ss) * S + sd : 0] * (ok ? 1.f : 0.f);
         }
         model[nt] = (nt * 16 + 4 * g) / SP;
     }
@@ -370,106 +410,126 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
         alpha[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    // ---- frame loads: two adjacent floats per r, kPrefetch steps in flight
-    // (one step is 2.5 KB per wave; HBM latency needs several of them queued)
+    // ---- frame queue: PF steps in flight.  The loop body is branch-free so the
+    // compiler keeps counted waits on it; steps past an utterance's end re-read
+    // its last frame and change nothing.
     constexpr int PF = 4;
-    const float* xbase = X + f0 * D + 2 * g;
-    float xq[PF][R][2];
-    auto load = [&](int t, float (&dst)[R][2]) {
+    u32x4 xq[PF][RQ];
+    auto load = [&](int t, u32x4 (&dst)[RQ]) {
         int tc = t < T ? t : T - 1;
         if (tc < 0) tc = 0;
-        const float* p = xbase + (int64_t)tc * D;
+        const unsigned o = row_off + (unsigned)tc * row_bytes;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int d0 = 8 * r + 2 * g;
-            dst[r][0] = d0 < D ? p[8 * r] : 0.f;
-            dst[r][1] = d0 + 1 < D ? p[8 * r + 1] : 0.f;
-        }
+        for (int q = 0; q < RQ; ++q)
+            dst[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 64u * q, 0, 0);
     };
 #pragma unroll
-    for (int k = 0; k < PF; ++k)
-        if (k < Tmax) load(k, xq[k]);
+    for (int k = 0; k < PF; ++k) load(k, xq[k]);
 
-    auto step = [&](int t, const float (&xc)[R][2]) {
-        // ---- split the frame: packed hi / lo halves of x and x^2
-        unsigned pxh[R], psh[R], pxl[R], psl[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const float x0 = xc[r][0], x1 = xc[r][1];
-            const float s0 = x0 * x0, s1 = x1 * x1;
-            const unsigned bx0 = __float_as_uint(x0), bx1 = __float_as_uint(x1);
-            const unsigned bs0 = __float_as_uint(s0), bs1 = __float_as_uint(s1);
-            pxh[r] = __builtin_amdgcn_perm(bx1, bx0, 0x07060302u);
-            psh[r] = __builtin_amdgcn_perm(bs1, bs0, 0x07060302u);
-            const bf16x2 xl = {(__bf16)(x0 - __uint_as_float(bx0 & 0xffff0000u)),
-                               (__bf16)(x1 - __uint_as_float(bx1 & 0xffff0000u))};
-            const bf16x2 sl = {(__bf16)(s0 - __uint_as_float(bs0 & 0xffff0000u)),
-                               (__bf16)(s1 - __uint_as_float(bs1 & 0xffff0000u))};
-            pxl[r] = __builtin_bit_cast(unsigned, xl);
-            psl[r] = __builtin_bit_cast(unsigned, sl);
-        }
+    // first: std::true_type for t == 0 (start probabilities instead of the transition product)
+    auto step = [&](auto first, int t, const u32x4 (&xc)[RQ]) {
         f32x4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = c0[nt];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            u32x4 f;
-            if (ks < R) {
-                f = u32x4{pxh[ks], psh[ks], pxl[ks], psl[ks]};
-            } else {
-                const int r0 = 2 * (ks - R), r1 = r0 + 1 < R ? r0 + 1 : r0;
-                f = u32x4{pxh[r0], psh[r0], pxh[r1], psh[r1]};   // a padded r' meets zero weights
+        for (int q = 0; q < RQ; ++q) {
+            // ---- split the lane's 4 features and their squares into bf16 halves
+            float x[4], sq[4];
+            unsigned xl_[2], sl_[2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                x[j] = __uint_as_float(xc[q][j]);
+                sq[j] = x[j] * x[j];
             }
-            const bf16x8 fb = __builtin_bit_cast(bf16x8, f);
+            u32x4 fh, fl;
+            fh[0] = __builtin_amdgcn_perm(xc[q][1], xc[q][0], 0x07060302u);
+            fh[1] = __builtin_amdgcn_perm(xc[q][3], xc[q][2], 0x07060302u);
+            fh[2] = __builtin_amdgcn_perm(__float_as_uint(sq[1]), __float_as_uint(sq[0]), 0x07060302u);
+            fh[3] = __builtin_amdgcn_perm(__float_as_uint(sq[3]), __float_as_uint(sq[2]), 0x07060302u);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x2 a = {(__bf16)(x[2 * j] - __uint_as_float(xc[q][2 * j] & 0xffff0000u)),
+                                  (__bf16)(x[2 * j + 1] - __uint_as_float(xc[q][2 * j + 1] & 0xffff0000u))};
+                const bf16x2 b = {
+                    (__bf16)(sq[2 * j] - __uint_as_float(__float_as_uint(sq[2 * j]) & 0xffff0000u)),
+                    (__bf16)(sq[2 * j + 1] - __uint_as_float(__float_as_uint(sq[2 * j + 1]) & 0xffff0000u))};
+                xl_[j] = __builtin_bit_cast(unsigned, a);
+                sl_[j] = __builtin_bit_cast(unsigned, b);
+            }
+            fl = u32x4{xl_[0], xl_[1], sl_[0], sl_[1]};
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, fh), bl = __builtin_bit_cast(bf16x8, fl);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, w[nt][ks]), fb, acc[nt], 0, 0, 0);
+                    __builtin_bit_cast(bf16x8, wh[nt][q]), bh, acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wh[nt][q]), bl, acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wl[nt][q]), bh, acc[nt], 0, 0, 0);
         }
+        // ---- recursion, all tiles stage by stage (independent chains interleave)
         const bool live = t < T;
+        float mx[NT], c[NT];
+        f32x4 na[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            float mx = fmaxf(fmaxf(acc[nt][0], acc[nt][1]), fmaxf(acc[nt][2], acc[nt][3]));
-            if (SP == 8) mx = fmaxf(mx, xchg16(mx));
-            f32x4 b, na;
+            mx[nt] = fmaxf(fmaxf(acc[nt][0], acc[nt][1]), fmaxf(acc[nt][2], acc[nt][3]));
+            if (SP == 8) mx[nt] = pair_max(mx[nt]);
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) b[r] = __builtin_amdgcn_exp2f(acc[nt][r] - mx);
-            if (t == 0) {
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 b;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b[r] = __builtin_amdgcn_exp2f(acc[nt][r] - mx[nt]);
+            if constexpr (decltype(first)::value) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = nt * 16 + 4 * g + r, m = row / SP, s = row % SP;
-                    na[r] = ((m < M && s < S) ? tb.pi[m * S + s] : 0.f) * b[r];
+                    const int row = nt * 16 + 4 * g + r, m = row / SP, s_ = row % SP;
+                    const bool ok = m < M && s_ < S;
+                    na[nt][r] = tb.pi[ok ? m * S + s_ : 0] * (ok ? 1.f : 0.f) * b[r];
                 }
             } else {
                 f32x4 p = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     p = __builtin_amdgcn_mfma_f32_16x16x4f32(atop[nt][q], alpha[nt][q], p, 0, 0, 0);
-                na = p * b;
+                na[nt] = p * b;
             }
-            float c = (na[0] + na[1]) + (na[2] + na[3]);
-            if (SP == 8) c += xchg16(c);
-            const float ci = __builtin_amdgcn_rcpf(c);
-            const double dl = (double)(mx + __builtin_amdgcn_logf(c));
-            if (live) {
-                lp[nt] += dl;
-                // alpha is the next step's matrix operand for EVERY row of this
-                // utterance's column: a dead chain (c == 0: padding rows of the
-                // tile, or a sequence the model cannot emit) must feed zeros,
-                // not NaN, or it would poison the other model of the tile.  Its
-                // own log-probability stays -inf / NaN as in the reference.
-                alpha[nt] = c > 0.f ? na * ci : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            c[nt] = (na[nt][0] + na[nt][1]) + (na[nt][2] + na[nt][3]);
+            if (SP == 8) c[nt] = pair_sum(c[nt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            // alpha is the next step's matrix operand for EVERY row of this
+            // utterance's column: a dead chain (c == 0: padding rows of the tile, or
+            // a sequence the model cannot emit) must feed zeros, not NaN, or it
+            // would poison the other model of the tile.  Its own log-probability
+            // stays -inf / NaN as in the reference.
+            const float ci = c[nt] > 0.f ? __builtin_amdgcn_rcpf(c[nt]) : 0.f;
+            const double dl = (double)(mx[nt] + __builtin_amdgcn_logf(c[nt]));
+            lp[nt] += live ? dl : 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) alpha[nt][r] = live ? na[nt][r] * ci : alpha[nt][r];
         }
     };
 
-    for (int t0 = 0; t0 < Tmax; t0 += PF) {
+    // t = 0, then groups of PF steps with static queue slots (slot = t mod PF)
+    if (Tmax > 0) {
+        step(std::true_type{}, 0, xq[0]);
+        load(PF, xq[0]);
+    }
+    for (int t0 = 1; t0 < Tmax; t0 += PF) {
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
-            if (t0 + k < Tmax) {
-                step(t0 + k, xq[k]);
-                if (t0 + k + PF < Tmax) load(t0 + k + PF, xq[k]);
-            }
+            step(std::false_type{}, t0 + k, xq[(1 + k) % PF]);
+            load(t0 + k + PF, xq[(1 + k) % PF]);
         }
     }
 
@@ -477,17 +537,19 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const bool writer = SP == 4 ? true : (g & 1) == 0;
-            if (writer && model[nt] < M) out[u * M + model[nt]] = lp[nt] * kLn2;
+            // a batch spanning 4 GiB or more cannot be addressed: report NaN, not garbage
+            if (writer && model[nt] < M)
+                out[u * M + model[nt]] = span_ok ? lp[nt] * kLn2 : __builtin_nan("");
         }
     }
 }
 
-template <int SP, int NT, int R>
+template <int SP, int NT, int RQ>
 void launch_split(const float* X, const int64_t* off, int64_t U, int64_t n_frames, int M, int S,
                   int D, SplitTables tb, double* out, hipStream_t st) {
     const int64_t groups = (U + 15) / 16;
     const unsigned grid = (unsigned)((groups + 3) / 4);
-    hipLaunchKernelGGL((score_split_kernel<SP, NT, R>), dim3(grid), dim3(256), 0, st, X, off, U,
+    hipLaunchKernelGGL((score_split_kernel<SP, NT, RQ>), dim3(grid), dim3(256), 0, st, X, off, U,
                        n_frames, M, S, D, tb, out);
 }
 
@@ -505,16 +567,17 @@ void launch(const float* X, const int64_t* off, int64_t U, int64_t n_frames, int
 int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
                    const srx_models_t* md, double* out, hipStream_t st) {
     const int M = md->n_models, S = md->n_states, D = md->n_features;
-    if (S > 8 || D > 40 || n_frames <= 0) return SRX_EUNSUPPORTED;
+    if (S > 8 || D > 48 || n_frames <= 0) return SRX_EUNSUPPORTED;
+    if (h->exact_f32 && D > 40) return SRX_EUNSUPPORTED;
     const int SP = S <= 4 ? 4 : 8;
     const int NT = (M * SP + 15) / 16;
     if (NT > 3) return SRX_EUNSUPPORTED;
     int R = (D + 7) / 8;
     if (R == 3) R = 4;
     if (R == 1) R = 2;
-    if (!h->exact_f32) {
-        const int KS = R + (R + 1) / 2;
-        const size_t n_wp = (size_t)NT * 16 * KS * 4 * 4, n_c = (size_t)NT * 16;
+    if (!h->exact_f32 && D <= 48) {
+        const int RQ = (D + 15) / 16;
+        const size_t n_wp = (size_t)NT * 16 * RQ * 2 * 4 * 4, n_c = (size_t)NT * 16;
         unsigned* base;
         int rc = srx_ws_ensure(h, WS_PARAMS,
                                4 * (n_wp + n_c + (size_t)M * S * S + (size_t)M * S), (void**)&base);
@@ -524,21 +587,21 @@ int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
         float* A = cst + n_c;
         float* pi = A + (size_t)M * S * S;
         tb.Wp = base; tb.cst = cst; tb.A = A; tb.pi = pi;
-        hipLaunchKernelGGL(split_prep_kernel, dim3(8), dim3(256), 0, st, *md, SP, NT, R, base, cst,
+        hipLaunchKernelGGL(split_prep_kernel, dim3(8), dim3(256), 0, st, *md, SP, NT, RQ, base, cst,
                            A, pi);
         const float* Xf = (const float*)X;
-#define SRX_CASE(sp, nt, r)                                                        \
-    if (SP == sp && NT == nt && R == r) {                                          \
-        launch_split<sp, nt, r>(Xf, off, U, n_frames, M, S, D, tb, out, st);       \
+#define SRX_CASE(sp, nt, rq)                                                       \
+    if (SP == sp && NT == nt && RQ == rq) {                                        \
+        launch_split<sp, nt, rq>(Xf, off, U, n_frames, M, S, D, tb, out, st);      \
         SRX_HIP(hipGetLastError());                                                \
         return SRX_OK;                                                             \
     }
-        SRX_CASE(8, 3, 5) SRX_CASE(8, 2, 5) SRX_CASE(8, 1, 5)
-        SRX_CASE(8, 3, 4) SRX_CASE(8, 2, 4) SRX_CASE(8, 1, 4)
+        SRX_CASE(8, 3, 3) SRX_CASE(8, 2, 3) SRX_CASE(8, 1, 3)
         SRX_CASE(8, 3, 2) SRX_CASE(8, 2, 2) SRX_CASE(8, 1, 2)
-        SRX_CASE(4, 3, 5) SRX_CASE(4, 2, 5) SRX_CASE(4, 1, 5)
-        SRX_CASE(4, 3, 4) SRX_CASE(4, 2, 4) SRX_CASE(4, 1, 4)
+        SRX_CASE(8, 3, 1) SRX_CASE(8, 2, 1) SRX_CASE(8, 1, 1)
+        SRX_CASE(4, 3, 3) SRX_CASE(4, 2, 3) SRX_CASE(4, 1, 3)
         SRX_CASE(4, 3, 2) SRX_CASE(4, 2, 2) SRX_CASE(4, 1, 2)
+        SRX_CASE(4, 3, 1) SRX_CASE(4, 2, 1) SRX_CASE(4, 1, 1)
 #undef SRX_CASE
         return SRX_EUNSUPPORTED;
     }
