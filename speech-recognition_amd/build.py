@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsrx.so")
-SOURCES = ["api.hip", "hmm_generic.hip", "score_mfma.hip", "estep_fused.hip", "mfcc.hip"]
+SOURCES = ["api.hip", "hmm_generic.hip", "score_mfma.hip", "estep_fused.hip", "mfcc.hip", "mfcc_fast.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall",
          "-Wno-unused-function", "-fvisibility=default",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC]

@@ -177,10 +177,15 @@ __device__ __forceinline__ T delta_at(const T* __restrict__ cep, int K, int64_t 
     return acc2 * inv_den;
 }
 
+// One workgroup per utterance.  Utterances whose cepstra and delta blocks fit
+// the LDS budget are finished there (one global read of the cepstra, one global
+// write of the features); longer ones go through global memory.
 template <typename T>
 __global__ void finish_kernel(const T* __restrict__ cep, const int64_t* __restrict__ so,
                               const int64_t* __restrict__ fo, int64_t U, MfccDev c, int order,
-                              int N, int zscore, T* __restrict__ out) {
+                              int N, int zscore, int lds_elems, T* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fin_raw[];
+    T* blk = (T*)fin_raw;                       // [1+order][Tu][K]
     __shared__ double red[256];
     __shared__ T col_mean[128], col_scale[128];
     const int K = c.n_ceps, NF = K * (1 + order);
@@ -194,48 +199,77 @@ __global__ void finish_kernel(const T* __restrict__ cep, const int64_t* __restri
         const int64_t To = Tu - 2 * trim > 0 ? Tu - 2 * trim : 0;
         const T* cu = cep + (s0 / c.hop) * K;
         T* ou = out + fo[u] * NF;
-        for (int64_t idx = threadIdx.x; idx < To * NF; idx += blockDim.x) {
-            const int64_t t = idx / NF;
-            const int f = (int)(idx % NF);
-            ou[idx] = delta_at<T>(cu, K, Tu, t + trim, f % K, f / K, N, inv_den);
-        }
-        if (!zscore || To == 0) continue;
-        __syncthreads();
-        // column sums: thread -> (column f, row group r)
-        const int groups = blockDim.x / NF;
-        const int f = threadIdx.x % NF, r = threadIdx.x / NF;
-        const bool active = r < groups;
-        for (int pass = 0; pass < 2; ++pass) {
-            double acc = 0.0;
-            if (active)
-                for (int64_t t = r; t < To; t += groups) {
-                    const double v = (double)ou[t * NF + f];
-                    if (pass == 0) acc += v;
-                    else { const double d = v - (double)col_mean[f]; acc += d * d; }
-                }
-            red[threadIdx.x] = acc;
-            __syncthreads();
-            if (threadIdx.x < NF) {
-                double s = 0.0;
-                for (int g = 0; g < groups; ++g) s += red[g * NF + threadIdx.x];
-                if (pass == 0) {
-                    col_mean[threadIdx.x] = (T)(s / (double)To);
-                } else {
-                    const T var = (T)(s / (double)To);
-                    const T mean = col_mean[threadIdx.x];
-                    const T e = eps_of<T>();
-                    const T bound = (T)To * e * var + ((T)To * mean * e) * ((T)To * mean * e);
-                    T sc = sqrt(var);
-                    if (var <= bound || sc == (T)0) sc = (T)1;   // constant column keeps scale 1
-                    col_scale[threadIdx.x] = sc;
+        if (To == 0) continue;
+        const bool in_lds = Tu * K * (1 + order) <= lds_elems;
+        const int TK = (int)(Tu * K);
+        if (in_lds) {
+            for (int i = threadIdx.x; i < TK; i += blockDim.x) blk[i] = cu[i];
+            for (int o = 1; o <= order; ++o) {
+                __syncthreads();
+                const T* src = blk + (size_t)(o - 1) * TK;
+                T* dst = blk + (size_t)o * TK;
+                for (int i = threadIdx.x; i < TK; i += blockDim.x) {
+                    const int t = i / K, k = i % K;
+                    T acc = 0;
+                    for (int j = -N; j <= N; ++j) acc += (T)j * src[(int)clamp_t(t + j, Tu) * K + k];
+                    dst[i] = acc * inv_den;
                 }
             }
             __syncthreads();
+        } else {
+            for (int64_t idx = threadIdx.x; idx < To * NF; idx += blockDim.x) {
+                const int64_t t = idx / NF;
+                const int f = (int)(idx % NF);
+                ou[idx] = delta_at<T>(cu, K, Tu, t + trim, f % K, f / K, N, inv_den);
+            }
+            __syncthreads();
         }
-        for (int64_t idx = threadIdx.x; idx < To * NF; idx += blockDim.x) {
-            const int ff = (int)(idx % NF);
-            ou[idx] = (ou[idx] - col_mean[ff]) / col_scale[ff];
+        // feature (t, f) of the kept frames
+        auto feat = [&](int64_t t, int f) -> T {
+            return in_lds ? blk[(size_t)(f / K) * TK + (t + trim) * K + f % K] : ou[t * NF + f];
+        };
+        if (zscore) {
+            // column sums: thread -> (column f, row group r)
+            const int groups = blockDim.x / NF;
+            const int f = threadIdx.x % NF, r = threadIdx.x / NF;
+            const bool active = r < groups;
+            for (int pass = 0; pass < 2; ++pass) {
+                double acc = 0.0;
+                if (active)
+                    for (int64_t t = r; t < To; t += groups) {
+                        const double v = (double)feat(t, f);
+                        if (pass == 0) acc += v;
+                        else { const double d = v - (double)col_mean[f]; acc += d * d; }
+                    }
+                red[threadIdx.x] = acc;
+                __syncthreads();
+                if (threadIdx.x < NF) {
+                    double s = 0.0;
+                    for (int g = 0; g < groups; ++g) s += red[g * NF + threadIdx.x];
+                    if (pass == 0) {
+                        col_mean[threadIdx.x] = (T)(s / (double)To);
+                    } else {
+                        const T var = (T)(s / (double)To);
+                        const T mean = col_mean[threadIdx.x];
+                        const T e = eps_of<T>();
+                        const T bound = (T)To * e * var + ((T)To * mean * e) * ((T)To * mean * e);
+                        T sc = sqrt(var);
+                        if (var <= bound || sc == (T)0) sc = (T)1;   // constant column keeps scale 1
+                        col_scale[threadIdx.x] = sc;
+                    }
+                }
+                __syncthreads();
+            }
+        } else if (threadIdx.x < NF) {
+            col_mean[threadIdx.x] = (T)0;
+            col_scale[threadIdx.x] = (T)1;
         }
+        __syncthreads();
+        if (in_lds || zscore)
+            for (int64_t idx = threadIdx.x; idx < To * NF; idx += blockDim.x) {
+                const int ff = (int)(idx % NF);
+                ou[idx] = (feat(idx / NF, ff) - col_mean[ff]) / col_scale[ff];
+            }
         __syncthreads();
     }
 }
@@ -331,6 +365,23 @@ int srx_mfcc_plan_create(srx_handle_t h, const srx_mfcc_cfg_t* cfg, srx_mfcc_pla
         ptr[m + 1] = (int32_t)w.size();
     }
     p->nnz = (int)w.size();
+    std::vector<int32_t> starts(cfg->n_mel, 0);
+    p->fast_ok = 1;
+    for (int m = 0; m < cfg->n_mel; ++m) {
+        const int q0 = ptr[m], q1 = ptr[m + 1];
+        starts[m] = q1 > q0 ? bins[q0] : 0;
+        for (int q = q0; q < q1; ++q)
+            if (bins[q] != starts[m] + (q - q0)) p->fast_ok = 0;
+    }
+    std::vector<float> twf(2 * (size_t)N);
+    for (int k = 0; k < N; ++k) {
+        twf[2 * k] = (float)cos(2.0 * M_PI * k / N);
+        twf[2 * k + 1] = (float)(-sin(2.0 * M_PI * k / N));
+    }
+    SRX_HIP(hipMalloc(&p->tw_full, sizeof(float) * twf.size()));
+    SRX_HIP(hipMemcpy(p->tw_full, twf.data(), sizeof(float) * twf.size(), hipMemcpyHostToDevice));
+    SRX_HIP(hipMalloc((void**)&p->mel_start, sizeof(int32_t) * starts.size()));
+    SRX_HIP(hipMemcpy(p->mel_start, starts.data(), sizeof(int32_t) * starts.size(), hipMemcpyHostToDevice));
     std::vector<double> dct((size_t)cfg->n_ceps * cfg->n_mel);
     for (int k = 0; k < cfg->n_ceps; ++k)
         for (int n = 0; n < cfg->n_mel; ++n) {
@@ -365,6 +416,8 @@ int srx_mfcc_plan_destroy(srx_mfcc_plan_t p) {
     }
     (void)hipFree(p->mel_bin);
     (void)hipFree(p->mel_ptr);
+    (void)hipFree(p->tw_full);
+    (void)hipFree(p->mel_start);
     delete p;
     return SRX_OK;
 }
@@ -414,24 +467,36 @@ int srx_mfcc_batch(srx_handle_t h, srx_mfcc_plan_t p, const void* audio, int dty
     int64_t grid = n_chunks < (int64_t)h->n_cu * 16 ? n_chunks : (int64_t)h->n_cu * 16;
     int64_t grid2 = n_utts < (int64_t)h->n_cu * 8 ? n_utts : (int64_t)h->n_cu * 8;
     const int idx = dtype == SRX_F64 ? 1 : 0;
+    const size_t fin_lds = 60 * 1024;
+    const int fin_elems = (int)(fin_lds / esz);
+    SRX_HIP(hipFuncSetAttribute((const void*)finish_kernel<float>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
+    SRX_HIP(hipFuncSetAttribute((const void*)finish_kernel<double>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
     if (dtype == SRX_F64) {
         hipLaunchKernelGGL(cepstra_kernel<double>, dim3((unsigned)grid), dim3(waves * kWave),
                            per_wave * waves, st, (const double*)audio, sample_offsets, n_utts,
                            n_samples, d, (const double*)p->window[idx],
                            (const cplx<double>*)p->twiddle[idx], (const double*)p->mel_w[idx],
                            (const double*)p->dct[idx], (double*)cep);
-        hipLaunchKernelGGL(finish_kernel<double>, dim3((unsigned)grid2), dim3(256), 0, st,
+        hipLaunchKernelGGL(finish_kernel<double>, dim3((unsigned)grid2), dim3(256), fin_lds, st,
                            (const double*)cep, sample_offsets, frame_offsets, n_utts, d,
-                           c.delta_order, c.delta_n, c.zscore, (double*)out_feats);
+                           c.delta_order, c.delta_n, c.zscore, fin_elems, (double*)out_feats);
     } else {
-        hipLaunchKernelGGL(cepstra_kernel<float>, dim3((unsigned)grid), dim3(waves * kWave),
-                           per_wave * waves, st, (const float*)audio, sample_offsets, n_utts,
-                           n_samples, d, (const float*)p->window[idx],
-                           (const cplx<float>*)p->twiddle[idx], (const float*)p->mel_w[idx],
-                           (const float*)p->dct[idx], (float*)cep);
-        hipLaunchKernelGGL(finish_kernel<float>, dim3((unsigned)grid2), dim3(256), 0, st,
+        rc = h->exact_f32 ? SRX_EUNSUPPORTED
+                          : srx_mfcc_fast_cepstra(h, p, (const float*)audio, sample_offsets, n_utts,
+                                                  n_samples, (float*)cep, st);
+        if (rc == SRX_EUNSUPPORTED)
+            hipLaunchKernelGGL(cepstra_kernel<float>, dim3((unsigned)grid), dim3(waves * kWave),
+                               per_wave * waves, st, (const float*)audio, sample_offsets, n_utts,
+                               n_samples, d, (const float*)p->window[idx],
+                               (const cplx<float>*)p->twiddle[idx], (const float*)p->mel_w[idx],
+                               (const float*)p->dct[idx], (float*)cep);
+        else if (rc)
+            return rc;
+        hipLaunchKernelGGL(finish_kernel<float>, dim3((unsigned)grid2), dim3(256), fin_lds, st,
                            (const float*)cep, sample_offsets, frame_offsets, n_utts, d,
-                           c.delta_order, c.delta_n, c.zscore, (float*)out_feats);
+                           c.delta_order, c.delta_n, c.zscore, fin_elems, (float*)out_feats);
     }
     SRX_HIP(hipGetLastError());
     return SRX_OK;

@@ -40,6 +40,10 @@ struct srx_mfcc_plan {
     int32_t* mel_ptr;      // [n_mel+1] CSR row pointers
     void* dct[2];          // [n_ceps, n_mel]
     int nnz;
+    // extras of the register-FFT kernel (float32)
+    void* tw_full;         // [nfft] complex exp(-2 pi i k / nfft)
+    int32_t* mel_start;    // [n_mel] first bin of each filter
+    int fast_ok;           // every filter is one contiguous run of bins
 };
 
 void srx_set_error(const char* fmt, ...);
@@ -105,3 +109,8 @@ int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
 int srx_fused_estep(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
                     const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* models,
                     double* out_stats, hipStream_t st);
+
+// Implemented in mfcc_fast.hip (float32, nfft 512 / 1024), else SRX_EUNSUPPORTED.
+int srx_mfcc_fast_cepstra(srx_context* h, srx_mfcc_plan* plan, const float* audio,
+                          const int64_t* sample_offsets, int64_t U, int64_t total, float* cep,
+                          hipStream_t st);

@@ -230,6 +230,22 @@ def test_mfcc_batch_ragged_equals_single(sra, ctx, mfcc_golden):
         if not np.any(s):
             continue   # all-zero input: columns are rounding noise, their z-score is arbitrary
         np.testing.assert_allclose(f2[off2[k]:off2[k + 1]], ref, rtol=0, atol=1e-7)
+    # float32: the register-FFT kernel (default) and the generic float32 kernel, un-normalised
+    cfg_raw = mo.MfccConfig(sample_rate=16000, nfft=512, n_mel=40, delta_order=2, zscore=False)
+    for exact in (False, True):
+        ctx.set_exact_f32(exact)
+        try:
+            f3, lens3 = sra.mfcc.extract_batch(sigs, 16000, nfft=512, n_mel=40, delta_order=2,
+                                               zscore=False, dtype="float32")
+        finally:
+            ctx.set_exact_f32(False)
+        off3 = np.concatenate([[0], np.cumsum(lens3)])
+        for k, s in enumerate(sigs):
+            ref = mo.extract(s.astype(np.float64), cfg_raw)
+            if ref.size == 0 or not np.any(s):
+                continue
+            np.testing.assert_allclose(f3[off3[k]:off3[k + 1]], ref, rtol=1e-4,
+                                       atol=1e-4 * np.abs(ref).max())
 
 
 def test_class_surface_and_errors(sra, ctx, hmm_golden):
