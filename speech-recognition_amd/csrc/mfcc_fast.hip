@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // ---- shared tables
     float2* s_tw = (float2*)smem_raw;                       // [N]
-    float* s_win = (float*)(s_tw + N);                      // [frame_len rounded to 4]
-    const int lpad = (c.frame_len + 3) & ~3;
+    float* s_win = (float*)(s_tw + N);                      // [N], zero past the samples the FFT uses
+    const int lpad = N;
     float* s_melw = s_win + lpad;                           // [nnz rounded to 4]
     const int wpad = (c.nnz + 3) & ~3;
     int* s_melptr = (int*)(s_melw + wpad);                  // [n_mel+1]
@@ -102,15 +102,18 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
     const int mpad = (c.n_mel + 3) & ~3;
     float* s_dct = (float*)(s_melstart + mpad);             // [n_ceps][n_mel+1]
     const int drow = c.n_mel + 1;
-    float* s_frames = s_dct + ((c.n_ceps * drow + 3) & ~3);
+    float2* s_tw2 = (float2*)(s_dct + ((c.n_ceps * drow + 3) & ~3));   // [P][16]: W_H^(j k1)
+    float* s_frames = (float*)(s_tw2 + P * 16);
     const int per_frame = 2 * YS + (H + 4) + ((c.n_mel + 3) & ~3);   // floats
     for (int i = threadIdx.x; i < N; i += blockDim.x) s_tw[i] = c.tw[i];
-    for (int i = threadIdx.x; i < c.frame_len; i += blockDim.x) s_win[i] = c.window[i];
+    for (int i = threadIdx.x; i < N; i += blockDim.x) s_win[i] = i < c.n_used ? c.window[i] : 0.f;
     for (int i = threadIdx.x; i < c.nnz; i += blockDim.x) s_melw[i] = c.mel_w[i];
     for (int i = threadIdx.x; i <= c.n_mel; i += blockDim.x) s_melptr[i] = c.mel_ptr[i];
     for (int i = threadIdx.x; i < c.n_mel; i += blockDim.x) s_melstart[i] = c.mel_start[i];
     for (int i = threadIdx.x; i < c.n_ceps * c.n_mel; i += blockDim.x)
         s_dct[(i / c.n_mel) * drow + i % c.n_mel] = c.dct[i];
+    for (int i = threadIdx.x; i < P * 16; i += blockDim.x)
+        s_tw2[i] = c.tw[2 * (((i & 15) * (i >> 4)) & (H - 1))];
     __syncthreads();
 
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
@@ -139,42 +142,51 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
             if (so[mid] <= p0) lo = mid; else hi = mid;
         }
         // ---- which frame does this lane group own?  (item-th frame starting in [p0, p1))
+        // The packed buffer holds < 2^32 samples here, so 32-bit division is enough.
         bool have = false;
-        int64_t s0 = 0, t = 0, row0 = 0;
+        int64_t s0 = 0;
+        unsigned t = 0, row0 = 0;
         int cnt = 0;
+        const unsigned hop = (unsigned)c.hop;
         for (int64_t u = lo; u < U && so[u] < p1 && !have; ++u) {
-            const int64_t us = so[u], n = so[u + 1] - us;
-            const int64_t Tu = raw_frames(n, c.frame_len, c.hop);
-            const int64_t a = p0 > us ? p0 - us : 0;
-            const int64_t ta = (a + c.hop - 1) / c.hop;
-            int64_t tb = (p1 - us + c.hop - 1) / c.hop;
+            const int64_t us = so[u];
+            const unsigned n = (unsigned)(so[u + 1] - us);
+            const unsigned Tu = n < (unsigned)c.frame_len ? 0u : (n - (unsigned)c.frame_len) / hop + 1u;
+            const unsigned a = p0 > us ? (unsigned)(p0 - us) : 0u;
+            const unsigned ta = (a + hop - 1u) / hop;
+            unsigned tb = ((unsigned)(p1 - us) + hop - 1u) / hop;
             if (tb > Tu) tb = Tu;
             const int nn = tb > ta ? (int)(tb - ta) : 0;
             if (item < cnt + nn) {
                 have = true;
                 s0 = us;
-                t = ta + (item - cnt);
-                row0 = us / c.hop;
+                t = ta + (unsigned)(item - cnt);
+                row0 = (unsigned)us / hop;
             }
             cnt += nn;
         }
         // ---- 1. load + window, bit-reversed register order, P-point FFT over n1
+        if (__ballot(have) == 0) continue;       // no frame starts in this chunk for this wave
+        // Loads are unconditional (a predicated load costs a branch and a full
+        // wait): indices are clamped into the frame and the zero tail of the
+        // window table removes what the FFT must not see.  A group without a
+        // frame reads the start of the buffer and stores nothing.
         float re[P], im[P];
-        const float* x = audio + s0 + t * c.hop;
+        const float* x = audio + s0 + (int64_t)(t * hop);
+        const int lim = have ? c.n_used - 1
+                             : (int)(total - 1 < (int64_t)c.n_used - 1 ? total - 1 : c.n_used - 1);
 #pragma unroll
         for (int n1 = 0; n1 < P; ++n1) {
             const int i0 = 32 * n1 + 2 * j;
-            float a0 = 0.f, a1 = 0.f;
-            if (have && i0 < c.n_used) a0 = x[i0] * s_win[i0];
-            if (have && i0 + 1 < c.n_used) a1 = x[i0 + 1] * s_win[i0 + 1];
-            re[brev(n1, ilog2(P))] = a0;
-            im[brev(n1, ilog2(P))] = a1;
+            const float2 wv = *(const float2*)(s_win + i0);
+            re[brev(n1, ilog2(P))] = x[min(i0, lim)] * wv.x;
+            im[brev(n1, ilog2(P))] = x[min(i0 + 1, lim)] * wv.y;
         }
         fft_regs<P>(re, im, twp);
         // ---- 2. twiddle W_H^(j k1) and 3. transpose through LDS: Y[k1][j]
 #pragma unroll
         for (int k1 = 0; k1 < P; ++k1) {
-            const float2 w = s_tw[2 * ((j * k1) & (H - 1))];
+            const float2 w = s_tw2[k1 * 16 + j];
             float2 v;
             v.x = w.x * re[k1] - w.y * im[k1];
             v.y = w.x * im[k1] + w.y * re[k1];
@@ -227,17 +239,20 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
         for (int m = j; m < c.n_mel; m += 16) {
             const int q0 = s_melptr[m], q1 = s_melptr[m + 1], b0 = s_melstart[m];
             float e = 0.f;
-            for (int q = q0; q < q1; ++q) e += pw[b0 + (q - q0)] * s_melw[q];
+            const float* pb = pw + b0 - q0;
+#pragma unroll 8
+            for (int q = q0; q < q1; ++q) e += pb[q] * s_melw[q];
             if (e == 0.f) e = 2.220446049250313e-16f;
             lm[m] = c.log_mult * __log10f(e);
         }
         wave_sync();
         // ---- DCT-II rows
         if (have) {
-            float* dst = cep + (row0 + t) * c.n_ceps;
+            float* dst = cep + (int64_t)(row0 + t) * c.n_ceps;
             for (int k = j; k < c.n_ceps; k += 16) {
                 float acc = 0.f;
                 const float* row = s_dct + k * drow;
+#pragma unroll 8
                 for (int m = 0; m < c.n_mel; ++m) acc += row[m] * lm[m];
                 dst[k] = acc;
             }
@@ -250,9 +265,9 @@ template <int P>
 int launch_fast(srx_context* h, const float* audio, const int64_t* so, int64_t U, int64_t total,
                 const FastDev& d, float* cep, hipStream_t st) {
     constexpr int H = 16 * P, N = 2 * H, YS = P * 17;
-    const int lpad = (d.frame_len + 3) & ~3, wpad = (d.nnz + 3) & ~3;
+    const int lpad = N, wpad = (d.nnz + 3) & ~3;
     const int mpad = (d.n_mel + 3) & ~3;
-    const size_t tables = sizeof(float2) * N +
+    const size_t tables = sizeof(float2) * N + sizeof(float2) * P * 16 +
                           4 * ((size_t)lpad + wpad + ((d.n_mel + 1 + 3) & ~3) + mpad +
                                ((d.n_ceps * (d.n_mel + 1) + 3) & ~3));
     const size_t per_frame = 4 * ((size_t)2 * YS + (H + 4) + mpad);
@@ -274,7 +289,7 @@ int launch_fast(srx_context* h, const float* audio, const int64_t* so, int64_t U
 int srx_mfcc_fast_cepstra(srx_context* h, srx_mfcc_plan* p, const float* audio, const int64_t* so,
                           int64_t U, int64_t total, float* cep, hipStream_t st) {
     const srx_mfcc_cfg_t& c = p->cfg;
-    if (!p->fast_ok || (c.nfft != 512 && c.nfft != 1024)) return SRX_EUNSUPPORTED;
+    if (!p->fast_ok || (c.nfft != 512 && c.nfft != 1024) || total >= 0xFFFFFFFFll) return SRX_EUNSUPPORTED;
     FastDev d;
     d.frame_len = c.frame_len; d.hop = c.hop;
     d.n_used = c.frame_len < c.nfft ? c.frame_len : c.nfft;
