@@ -1,15 +1,17 @@
-// Fused Baum-Welch E-step on the matrix cores (float32 data, S <= 16, D <= 40).
+// Fused Baum-Welch E-step on the matrix cores (float32 data, S <= 16, D <= 48).
 //
 // One wave processes 16 utterances of ONE model at a time, step by step:
-//   forward   emission contraction (as in score_mfma.hip) -> b~_t, then
+//   forward   emission contraction -> b~_t, then
 //             alpha_t = (A^T alpha_{t-1}) * b~_t / c_t with the 16x16 mat-vec
 //             as 4 MFMAs; alpha_t and 1/c_t are spilled ([frames,16] floats).
 //   backward  emission again (cheaper than spilling it), beta_t = c_t A (b~ beta)_{t+1}
-//             as 4 MFMAs, gamma_t, and three accumulating products whose
+//             as 4 MFMAs, gamma_t, and two accumulating products whose
 //             contraction index is the utterance:
 //                 G   += alpha_t   (b~ beta)_{t+1}^T      (16 x 16)     4 MFMAs
-//                 obs += gamma_t   [x_t | x_t^2]          (16 x 2 DP)  4R MFMAs
+//                 obs += gamma_t   [x_t | x_t^2]          (16 x 2D)   4 NTX MFMAs
 //             (xi sums are A o G, applied once at the end).
+// All products run on exact-f32 MFMAs (v_mfma_f32_16x16x4_f32): re-estimated
+// parameters have to hold 1e-5 relative, which a bf16-split emission misses.
 // State placement.  MFMA row r of the 16-row tile carries state 4*(r&3)+(r>>2), so
 // the accumulator register q of lane group g (rows 4g..4g+3) is state 4q+g --
 // exactly the k index that lane group supplies as the B operand of k-step q.
@@ -17,50 +19,78 @@
 // registers, no lane movement.  Products that contract over utterances need the
 // utterance on the k axis instead of the lane: alpha, gamma, b~beta and the
 // frame go through small per-wave LDS tiles ([utterance][row]) for that.
+// Memory.  The feature axis is cut into RQ blocks of 16 plus, if H, one of 8.
+// Lane group g reads features 16q+4g..+3 of a block with one 16-byte raw buffer
+// load (8q'+2g..+1 with an 8-byte load in the half block); loads are range-
+// checked and rows are only 4-byte aligned.  Frames,
+// and in the backward pass the spilled alpha and scale, are requested PF steps
+// ahead in a branch-free loop so the waits stay counted.
+// Spilled lattice.  A batch owns as many lattice rows as its utterances have
+// frames, starting at the exclusive prefix sum of the batch totals (a small scan
+// kernel).  Inside, rows are time-major and dense: step t occupies the next
+// nlive(t) rows, one per utterance still running, in lane order.  A wave's
+// store is then one contiguous run of 64-byte rows (1 KiB when all 16 run) and
+// every cache line is complete after at most two steps -- rows laid out per
+// utterance leave half-written lines behind that L2 evicts and refills many times.
 // Accumulation: f32 inside the MFMAs over one batch of 16 utterances, then
-// added to a per-wave float64 record in LDS (each element owned by one lane),
-// which is flushed with f64 atomics into one of kReplicas global records when
-// the wave's model changes or its work ends; a last kernel sums the replicas in
-// fixed order and applies A to G.
+// added with f64 atomics to one of kReplicas global records of the batch's
+// model; a last kernel sums the replicas in fixed order and applies A to G.
 #include "srx_internal.h"
 
 #include <math.h>
+#include <type_traits>
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kReplicas = 64;
 constexpr int kWavesPerBlock = 4;
+constexpr int PF = 3;
 constexpr float kNegBig = -1.0e30f;
 constexpr double kLn2 = 0.6931471805599453;
 
 __host__ __device__ inline int sigma(int row) { return 4 * (row & 3) + (row >> 2); }
 
 struct FusedTables {
-    const float* W;     // [M][16 rows][4R][4]
-    const float* cst;   // [M][16 rows]
-    const float* A;     // [M][16][16] zero padded, state order
-    const float* pi;    // [M][16]
+    const float* W;      // [M][16 rows][KW = 8 RQ + 4 H][4 lane groups]
+    const float* cst;    // [M][16 rows]
+    const float* A;      // [M][16][16] zero padded, state order
+    const float* pi;     // [M][16]
 };
 
-__global__ void fused_prep_kernel(srx_models_t md, int R, float* W, float* cst, float* A,
+// Feature and kind (0: mean/var weight of x, 1: -1/(2 var) weight of x^2) that
+// k-step kk of lane group g contracts.
+__host__ __device__ inline void kstep_feature(int RQ, int kk, int g, int* d, int* kind) {
+    if (kk < 8 * RQ) {
+        *d = 16 * (kk >> 3) + 4 * g + (kk & 3);
+        *kind = (kk >> 2) & 1;
+    } else {
+        const int e = kk - 8 * RQ;
+        *d = 16 * RQ + 2 * g + (e & 1);
+        *kind = e >> 1;
+    }
+}
+
+__global__ void fused_prep_kernel(srx_models_t md, int RQ, int H, float* W, float* cst, float* A,
                                   float* pi) {
     const int M = md.n_models, S = md.n_states, D = md.n_features;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nth = gridDim.x * blockDim.x;
-    const int KQ = 4 * R;
-    for (int i = tid; i < M * 16 * KQ * 4; i += nth) {
-        const int g = i & 3, q = (i >> 2) % KQ, row = ((i >> 2) / KQ) % 16, m = (i >> 2) / KQ / 16;
+    const int KW = 8 * RQ + 4 * H;
+    for (int i = tid; i < M * 16 * KW * 4; i += nth) {
+        const int g = i & 3, kk = (i >> 2) % KW, row = ((i >> 2) / KW) % 16, m = (i >> 2) / KW / 16;
         const int s = sigma(row);
-        const int r = q >> 2, e = q & 3;
-        const int d = 8 * r + 2 * g + (e & 1);
+        int d, kind;
+        kstep_feature(RQ, kk, g, &d, &kind);
         float v = 0.f;
         if (s < S && d < D) {
             const size_t k = ((size_t)m * S + s) * D + d;
             const double var = fmax(md.covars[k], 2.2250738585072014e-308);
-            v = (float)((e >> 1) ? (-0.5 / var) * 1.4426950408889634
-                                 : (md.means[k] / var) * 1.4426950408889634);
+            v = (float)(kind ? (-0.5 / var) * 1.4426950408889634
+                             : (md.means[k] / var) * 1.4426950408889634);
         }
         W[i] = v;
     }
@@ -91,17 +121,27 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ float sum16(f32x4 v) {   // over the 16 states of an utterance
+// Reductions over the 16 states of an utterance: lanes l, l^16, l^32, l^48,
+// 4 registers each.  v_permlane16_swap / v_permlane32_swap of two copies of a
+// value leave {v[l], v[partner]} in the two results, so commutative reductions
+// need no LDS round trip.
+__device__ __forceinline__ float sum16(f32x4 v) {
     float s = (v[0] + v[1]) + (v[2] + v[3]);
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    return s;
+    unsigned u = __float_as_uint(s);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    u = __float_as_uint(s);
+    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float max16(f32x4 v) {
     float s = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-    s = fmaxf(s, __shfl_xor(s, 16, 64));
-    s = fmaxf(s, __shfl_xor(s, 32, 64));
-    return s;
+    unsigned u = __float_as_uint(s);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    s = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    u = __float_as_uint(s);
+    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float sum_u(float v) {   // over the 16 utterance lanes of a group
     v += __shfl_xor(v, 1, 64);
@@ -111,26 +151,29 @@ __device__ __forceinline__ float sum_u(float v) {   // over the 16 utterance lan
     return v;
 }
 
-template <int R>
+// Row stride of the frame tile in floats.
+__host__ __device__ constexpr int frame_tile_stride(int dp) { return dp <= 16 ? 16 : 48; }
+
+template <int RQ, int H>
+struct Frame {
+    u32x4 v[RQ ? RQ : 1];
+    u32x2 h;
+};
+
+template <int RQ, int H, int NTX>
 __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
     const float* __restrict__ X, const int64_t* __restrict__ off, int64_t U, int64_t n_frames,
     const int32_t* __restrict__ utt_model, const int64_t* __restrict__ utt_order, int M, int S,
-    int D, FusedTables tb, float* __restrict__ lat, float* __restrict__ scale,
-    double* __restrict__ replicas, int rec_size) {
-    constexpr int KQ = 4 * R;      // emission k-steps
-    constexpr int DP = 8 * R;      // padded feature count
-    constexpr int XW = DP;         // row of the frame tile (squares are formed on read)
-    constexpr int NTX = R;         // 16-column tiles of the frame tile
+    int D, FusedTables tb, const int64_t* __restrict__ batch_base, float* __restrict__ lat,
+    float* __restrict__ scale, double* __restrict__ replicas, int rec_size) {
+    constexpr int DP = 16 * RQ + 8 * H;   // padded feature count
+    constexpr int KW = 8 * RQ + 4 * H;    // emission k-steps
+    constexpr int XS = frame_tile_stride(DP);
+    constexpr int TILE = 3 * 256 + 16 * XS;   // floats: gamma, alpha, b~beta tiles and the frame tile
+    typedef Frame<RQ, H> frame_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, ul = lane & 15;
-    const int rec_pad = (rec_size + 1) & ~1;
-    const size_t wave_bytes = sizeof(double) * rec_pad + sizeof(float) * (3 * 256 + 16 * XW);
-    double* acc = (double*)(smem_raw + wave_bytes * wv);
-    float* t_gam = (float*)(acc + rec_pad);
-    float* t_alp = t_gam + 256;
-    float* t_bb = t_alp + 256;
-    float* t_x = t_bb + 256;
-    for (int i = lane; i < rec_size; i += 64) acc[i] = 0.0;
+    float* tiles = (float*)smem_raw + (size_t)wv * 2 * TILE;   // two buffers per wave
 
     const srx_stats_layout L(S, D);
     const int64_t n_groups = (U + 15) / 16;
@@ -139,27 +182,22 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
     const int64_t per = (n_groups + n_waves - 1) / n_waves;
     const int64_t k0 = wid * per, k1 = (k0 + per < n_groups) ? k0 + per : n_groups;
     double* my_rep = replicas + (size_t)(wid % kReplicas) * M * rec_size;
+    const unsigned row_bytes = (unsigned)D * 4u;
+    const unsigned below = (1u << ul) - 1u;       // lanes of lower utterances
+    // Tile element (utt, r) sits at utt * stride + (r ^ 4 (utt >> 2)): the 16-byte
+    // writes (utt = ul, r = 4g..) and the dword reads (utt = 4q + g, r = ul) are
+    // then both free of bank conflicts (frame tile: stride 16 or 48 mod 64).
+    const int wsw = 4 * g ^ 4 * (ul >> 2);
+    const int hsw = 2 * g ^ 4 * (ul >> 2);
 
     int cur_model = -1;
-    float w[KQ];
+    float w[KW];
     f32x4 c0, pi4;
     float atop[4], aop[4];
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) w[q] = 0.f;
+    for (int q = 0; q < KW; ++q) w[q] = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { atop[q] = aop[q] = 0.f; c0[q] = 0.f; pi4[q] = 0.f; }
-
-    auto flush_global = [&]() {
-        if (cur_model < 0) return;
-        wave_sync();
-        double* dst = my_rep + (size_t)cur_model * rec_size;
-        for (int i = lane; i < rec_size; i += 64) {
-            const double v = acc[i];
-            if (v != 0.0) unsafeAtomicAdd(dst + i, v);
-            acc[i] = 0.0;
-        }
-        wave_sync();
-    };
 
     for (int64_t k = k0; k < k1; ++k) {
         const int64_t e = k * 16 + ul;
@@ -169,19 +207,33 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
         const int64_t f_start = valid ? off[u] : 0;
         const int T_l = valid ? (int)(off[u + 1] - f_start) : 0;
         bool pending = valid && T_l > 0;
+        const int64_t row_base = batch_base[k];
         while (true) {
             const unsigned long long mask = __ballot(pending);
             if (mask == 0) break;
             const int first = __ffsll((long long)mask) - 1;
             const int m_cur = __shfl(m_l, first, 64);
-            const bool active = pending && m_l == m_cur;
+            // One descriptor addresses 4 GiB: of this model's utterances take those
+            // within reach of the lowest one now, the rest in a later pass.
+            const bool cand = pending && m_l == m_cur;
+            int64_t fmin = cand ? f_start : (int64_t)0x7FFFFFFFFFFFFFFFll;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const int64_t a = __shfl_xor(fmin, o, 64);
+                fmin = a < fmin ? a : fmin;
+            }
+            const int64_t frame_bytes = D > 16 ? (int64_t)D * 4 : 64;   // widest of X, lattice rows
+            const bool fits = cand && (f_start + T_l - fmin) * frame_bytes < 0xFFFFFF00ll &&
+                              T_l < (1 << 22);   // 16 of them: lattice offsets stay 32-bit
+            const bool span_ok = __ballot(fits) != 0;
+            // (a single utterance beyond 4 GiB is not supported: its statistics are NaN)
+            const bool active = span_ok ? fits : (cand && f_start == fmin);
             pending = pending && !active;
             if (m_cur != cur_model) {
-                flush_global();
                 cur_model = m_cur;
-                const float* Wm = tb.W + (size_t)m_cur * 16 * KQ * 4;
+                const float* Wm = tb.W + (size_t)m_cur * 16 * KW * 4;
 #pragma unroll
-                for (int q = 0; q < KQ; ++q) w[q] = Wm[((size_t)ul * KQ + q) * 4 + g];
+                for (int q = 0; q < KW; ++q) w[q] = Wm[((size_t)ul * KW + q) * 4 + g];
                 const float* Am = tb.A + (size_t)m_cur * 256;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -194,146 +246,247 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                 }
             }
             const int T = active ? T_l : 0;
-            int64_t f0 = active ? f_start : 0;
-            if (f0 > n_frames - 1) f0 = n_frames - 1;
             int Tmax = T;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o, 64));
 
-            const float* xbase = X + f0 * D;
-            float* latp = lat + f0 * 16 + 4 * g;
-            float* scp = scale + f0;
-            float xc[R][2], xn[R][2];
-            auto load = [&](int t, float (&dst)[R][2]) {
+            // ---- descriptors: X from the lowest first row of the batch to its end,
+            // the lattice from this batch's first row.  Offsets from kDrop up are out
+            // of range for every one of them, which drops a store.
+            constexpr unsigned kDrop = 0xFFFFFF00u;
+            const auto make_rsrc = [&](const void* p, int64_t bytes) {
+                const uintptr_t a = (uintptr_t)p;
+                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+                const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+                const unsigned n = (unsigned)(bytes < (int64_t)kDrop ? bytes : (int64_t)kDrop);
+                return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0,
+                                                         __builtin_amdgcn_readfirstlane(n), 0x00020000);
+            };
+            const __amdgpu_buffer_rsrc_t rsrc =
+                make_rsrc(X + fmin * D, span_ok ? (n_frames - fmin) * (int64_t)D * 4 : 0);
+            const __amdgpu_buffer_rsrc_t rsrc_lat = make_rsrc(lat + row_base * 16, (n_frames - row_base) * 64);
+            const __amdgpu_buffer_rsrc_t rsrc_sc = make_rsrc(scale + row_base, (n_frames - row_base) * 4);
+            const int64_t f0 = active ? f_start : fmin;
+            const unsigned lane_off = (unsigned)((f0 - fmin) * D * 4) + 16u * g;   // + 64 q for block q
+            const unsigned half_off = (unsigned)((f0 - fmin) * D * 4) + 64u * RQ + 8u * g;
+            auto loadx = [&](int t, frame_t& dst) {
                 int tc = t < T ? t : T - 1;
                 if (tc < 0) tc = 0;
-                const float* p = xbase + (int64_t)tc * D;
+                const unsigned o = (unsigned)tc * row_bytes;
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    // features past D meet zero weights: read a valid neighbour
-                    // instead of predicating the load
-                    dst[r][0] = p[min(8 * r + 2 * g, D - 1)];
-                    dst[r][1] = p[min(8 * r + 2 * g + 1, D - 1)];
-                }
+                for (int q = 0; q < RQ; ++q)
+                    dst.v[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off + o + 64u * q, 0, 0);
+                if constexpr (H != 0) dst.h = __builtin_amdgcn_raw_buffer_load_b64(rsrc, half_off + o, 0, 0);
             };
-            auto emission = [&](const float (&x)[R][2]) {
-                f32x4 a4 = c0;
+            // b~ in log2 units for one frame; features past D meet zero weights.
+            // (two accumulators: a dependent MFMA issues every 40 cycles, an
+            // independent one every 32)
+            auto emission = [&](const frame_t& xc) {
+                f32x4 a4 = c0, a5 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const float x0 = x[r][0], x1 = x[r][1];
-                    a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[4 * r + 0], x0, a4, 0, 0, 0);
-                    a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[4 * r + 1], x1, a4, 0, 0, 0);
-                    a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[4 * r + 2], x0 * x0, a4, 0, 0, 0);
-                    a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[4 * r + 3], x1 * x1, a4, 0, 0, 0);
+                for (int q = 0; q < RQ; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float x = __uint_as_float(xc.v[q][j]);
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[8 * q + j], x, a4, 0, 0, 0);
+                        a5 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[8 * q + 4 + j], x * x, a5, 0, 0, 0);
+                    }
                 }
-                return a4;
+                if constexpr (H != 0) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float x = __uint_as_float(xc.h[j]);
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[8 * RQ + j], x, a4, 0, 0, 0);
+                        a5 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[8 * RQ + 2 + j], x * x, a5, 0, 0, 0);
+                    }
+                }
+                return a4 + a5;
+            };
+            auto matvec = [&](const float (&aw)[4], const f32x4& v) {
+                f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
+                p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[0], v[0], p0, 0, 0, 0);
+                p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[1], v[1], p1, 0, 0, 0);
+                p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[2], v[2], p0, 0, 0, 0);
+                p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[3], v[3], p1, 0, 0, 0);
+                return p0 + p1;
             };
 
             // ------------------------------------------------------ forward
             f32x4 alpha = {0.f, 0.f, 0.f, 0.f};
             double lp = 0.0;
-            load(0, xc);
-            for (int t = 0; t < Tmax; ++t) {
-                if (t + 1 < Tmax) load(t + 1, xn);
+            unsigned rows_done = 0;                       // wave-uniform
+            frame_t xq[PF];
+            // (scheduling fences: the queue must fill oldest slot first, or the
+            // loop's first wait has to cover every load in flight)
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                loadx(i, xq[i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            auto fwd = [&](auto first, int t, const frame_t& xc) {
                 const f32x4 ll = emission(xc);
                 const float mx = max16(ll);
                 f32x4 b, a4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) b[r] = __builtin_amdgcn_exp2f(ll[r] - mx);
-                if (t == 0) {
+                if constexpr (decltype(first)::value) {
                     a4 = pi4 * b;
                 } else {
-                    f32x4 p = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        p = __builtin_amdgcn_mfma_f32_16x16x4f32(atop[q], alpha[q], p, 0, 0, 0);
-                    a4 = p * b;
+                    a4 = matvec(atop, alpha) * b;
                 }
                 const float c = sum16(a4);
-                const float ci = 1.0f / c;
-                if (t < T) {
-                    lp += (double)(mx + __builtin_amdgcn_logf(c));
-                    alpha = a4 * ci;
-                    *(f32x4*)(latp + (int64_t)t * 16) = alpha;
-                    if (g == 0) scp[t] = ci;
-                }
+                const float ci = __builtin_amdgcn_rcpf(c);
+                const bool live = t < T;
+                lp += live ? (double)(mx + __builtin_amdgcn_logf(c)) : 0.0;
+                alpha = live ? a4 * ci : alpha;
+                const unsigned lm = (unsigned)__ballot(live) & 0xFFFFu;
+                const unsigned row = rows_done + __builtin_popcount(lm & below);
+                rows_done += __builtin_popcount(lm);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, alpha), rsrc_lat,
+                                                       live ? row * 64u + 16u * g : kDrop, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ci), rsrc_sc,
+                                                      live && g == 0 ? row * 4u : kDrop, 0, 0);
+            };
+            if (Tmax > 0) {
+                fwd(std::true_type{}, 0, xq[0]);
+                loadx(PF, xq[0]);
+            }
+            for (int t0 = 1; t0 < Tmax; t0 += PF) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) { xc[r][0] = xn[r][0]; xc[r][1] = xn[r][1]; }
+                for (int i = 0; i < PF; ++i) {
+                    fwd(std::false_type{}, t0 + i, xq[(1 + i) % PF]);
+                    loadx(t0 + i + PF, xq[(1 + i) % PF]);
+                }
             }
 
             // ----------------------------------------------------- backward
+            // Two steps per iteration.  Step t is produced (recursion, then its
+            // gamma / alpha / b~beta / frame tiles written to buffer t & 1 ...) while
+            // the tiles of step t + 1 in the other buffer are consumed by the
+            // accumulating MFMAs: two independent instruction streams between
+            // consecutive wave syncs.
             f32x4 bb = {0.f, 0.f, 0.f, 0.f}, post = bb, start = bb, G = bb;
             f32x4 O[NTX];
 #pragma unroll
             for (int nt = 0; nt < NTX; ++nt) O[nt] = bb;
-            if (Tmax > 0) load(Tmax - 1, xc);
-            for (int t = Tmax - 1; t >= 0; --t) {
-                if (t > 0) load(t - 1, xn);
-                const bool live = t < T;
+            f32x4 alq[2];
+            float ciq[2];
+            // Loads are issued in strictly descending t, so one running row counter
+            // serves them.
+            auto loadb = [&](int t, frame_t& xd, f32x4& ad, float& cd) {
+                const unsigned lm = (unsigned)__ballot(t >= 0 && t < T) & 0xFFFFu;
+                rows_done -= __builtin_popcount(lm);
+                const unsigned row = rows_done + __builtin_popcount(lm & below);
+                loadx(t, xd);
+                ad = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   rsrc_lat, row * 64u + 16u * g, 0, 0));
+                cd = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_sc, row * 4u, 0, 0));
+            };
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                loadb(Tmax - 1 - i, xq[i], alq[i], ciq[i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the first consume reads buffer 1: start it from zeros
+            for (int i = lane; i < TILE / 4; i += 64) ((f32x4*)(tiles + TILE))[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            wave_sync();
+
+            // (tile reads are issued as a group ahead of the MFMAs that use them)
+            auto consume = [&](const float* tl) {
+                const float* t_gam = tl;
+                const float* t_alp = tl + 256;
+                const float* t_bb = tl + 512;
+                const float* t_x = tl + 768;
+#pragma unroll
+                for (int qh = 0; qh < 4; qh += 2) {
+                    float ga[2], aa[2], ba[2], xa[2][NTX];
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const int q = qh + qq;
+                        const int row = (4 * q + g) * 16 + (ul ^ 4 * q);
+                        aa[qq] = t_alp[row];
+                        ba[qq] = t_bb[row];
+                        ga[qq] = t_gam[row];
+#pragma unroll
+                        for (int nt = 0; nt < NTX; ++nt) {
+                            // column c of [x (DP wide) | x^2 (DP wide)]
+                            const int c = 16 * nt + ul;
+                            const int d = c < DP ? c : c - DP;
+                            xa[qq][nt] = t_x[(4 * q + g) * XS + (d ^ 4 * q)];
+                        }
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (3 + NTX), 0);   // DS reads
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        G = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[qq], ba[qq], G, 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < NTX; ++nt) {
+                            float xv = xa[qq][nt];
+                            if (16 * nt + ul >= DP) xv *= xv;
+                            O[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[qq], xv, O[nt], 0, 0, 0);
+                        }
+                    }
+                }
+            };
+            auto produce = [&](int t, float* tl, const frame_t& xc, const f32x4& al_in, float ci_in) {
+                float* t_gam = tl;
+                float* t_alp = tl + 256;
+                float* t_bb = tl + 512;
+                float* t_x = tl + 768;
+                const bool live = t < T && t >= 0;
                 const f32x4 ll = emission(xc);
                 const float mx = max16(ll);
-                f32x4 b, al = {0.f, 0.f, 0.f, 0.f};
+                f32x4 b;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) b[r] = __builtin_amdgcn_exp2f(ll[r] - mx);
-                float ci = 0.f;
-                if (live) {
-                    al = *(const f32x4*)(latp + (int64_t)t * 16);
-                    ci = scp[t];
-                }
-                f32x4 p = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    p = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[q], bb[q], p, 0, 0, 0);
-                f32x4 beta = p * ci;
+                const f32x4 al = live ? al_in : f32x4{0.f, 0.f, 0.f, 0.f};
+                const float ci = live ? ci_in : 0.f;
+                f32x4 beta = matvec(aop, bb) * ci;
                 if (t == T - 1) beta = f32x4{ci, ci, ci, ci};
                 f32x4 gam = al * beta;
                 float gs = sum16(gam);
                 if (gs == 0.f) gs = 1.f;          // utils.normalize: zero rows divide by 1
-                gam = gam / gs;
-                // tiles with the utterance as row: [ul][4g .. 4g+3]
-                *(f32x4*)(t_gam + ul * 16 + 4 * g) = gam;
-                *(f32x4*)(t_alp + ul * 16 + 4 * g) = al;
-                *(f32x4*)(t_bb + ul * 16 + 4 * g) = bb;
+                gam = gam * __builtin_amdgcn_rcpf(gs);
+                *(f32x4*)(t_gam + ul * 16 + wsw) = gam;
+                *(f32x4*)(t_alp + ul * 16 + wsw) = al;
+                *(f32x4*)(t_bb + ul * 16 + wsw) = bb;
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const float x0 = live ? xc[r][0] : 0.f, x1 = live ? xc[r][1] : 0.f;
-                    *(float2*)(t_x + ul * XW + 8 * r + 2 * g) = make_float2(x0, x1);
+                for (int q = 0; q < RQ; ++q) {
+                    // (a finished utterance keeps its last frame here: its gamma is 0)
+                    *(u32x4*)(t_x + ul * XS + 16 * q + wsw) = xc.v[q];
                 }
-                wave_sync();
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int row = (4 * q + g) * 16 + ul;
-                    G = __builtin_amdgcn_mfma_f32_16x16x4f32(t_alp[row], t_bb[row], G, 0, 0, 0);
-                    const float gq = t_gam[row];
-#pragma unroll
-                    for (int nt = 0; nt < NTX; ++nt) {
-                        // column c of [x | x^2]: c < DP is x_c, else x_(c-DP) squared
-                        const int c = 16 * nt + ul;
-                        float xv = t_x[(4 * q + g) * XW + (c < DP ? c : c - DP)];
-                        if (c >= DP) xv *= xv;
-                        O[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gq, xv, O[nt], 0, 0, 0);
-                    }
+                if constexpr (H != 0) {
+                    *(u32x2*)(t_x + ul * XS + 16 * RQ + hsw) = xc.h;
                 }
                 post += gam;
                 if (t == 0) start = gam;
                 bb = live ? b * beta : f32x4{0.f, 0.f, 0.f, 0.f};
-                wave_sync();
+            };
+            for (int t0 = Tmax - 1; t0 >= 0; t0 -= 2) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) { xc[r][0] = xn[r][0]; xc[r][1] = xn[r][1]; }
+                for (int i = 0; i < 2; ++i) {
+                    const int t = t0 - i;             // t = -1: a dead step, writes zero tiles
+                    consume(tiles + TILE * (i ^ 1));
+                    produce(t, tiles + TILE * i, xq[i], alq[i], ciq[i]);
+                    loadb(t - 2, xq[i], alq[i], ciq[i]);
+                    wave_sync();
+                }
             }
+            consume(tiles + TILE);                    // the last step produced
 
-            // ------------------------ batch sums -> per-wave float64 record
+            // ---------------- batch sums -> this wave's global float64 record
             // G and O are in accumulator layout: lane (g, ul) holds rows 4g+reg, column ul.
+            double* dst = my_rep + (size_t)m_cur * rec_size;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int si = sigma(4 * g + reg), sj = sigma(ul);
-                if (si < S && sj < S) acc[L.trans + si * S + sj] += (double)G[reg];
+                if (si < S && sj < S) unsafeAtomicAdd(dst + L.trans + si * S + sj, (double)G[reg]);
 #pragma unroll
                 for (int nt = 0; nt < NTX; ++nt) {
                     const int c = 16 * nt + ul;
                     const int d = c < DP ? c : c - DP;
                     if (si < S && d < D)
-                        acc[(c < DP ? L.obs : L.obs2) + si * D + d] += (double)O[nt][reg];
+                        unsafeAtomicAdd(dst + (c < DP ? L.obs : L.obs2) + si * D + d, (double)O[nt][reg]);
                 }
             }
 #pragma unroll
@@ -341,24 +494,65 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                 const float ps = sum_u(post[reg]), ss = sum_u(start[reg]);
                 const int s = 4 * reg + g;
                 if (ul == 0 && s < S) {
-                    acc[L.post + s] += (double)ps;
-                    acc[L.start + s] += (double)ss;
+                    unsafeAtomicAdd(dst + L.post + s, (double)ps);
+                    unsafeAtomicAdd(dst + L.start + s, (double)ss);
                 }
             }
             {
-                double lps = lp;
+                double lps = span_ok ? lp : __builtin_nan("");
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) lps += __shfl_xor(lps, o, 64);
                 const unsigned long long am = __ballot(active);
                 if (lane == 0) {
-                    acc[L.logprob] += lps * kLn2;
-                    acc[L.nobs] += (double)__popcll(am & 0xFFFFull);
+                    unsafeAtomicAdd(dst + L.logprob, lps * kLn2);
+                    unsafeAtomicAdd(dst + L.nobs, (double)__popcll(am & 0xFFFFull));
                 }
             }
             wave_sync();
         }
     }
-    flush_global();
+}
+
+// Lattice row bases: frames per batch of 16 utterances (in processing order),
+// then an exclusive prefix sum by one block.
+__global__ void fused_batch_total_kernel(const int64_t* __restrict__ off, int64_t U,
+                                         const int64_t* __restrict__ utt_order, int64_t n_batches,
+                                         int64_t* __restrict__ base) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_batches) return;
+    int64_t sum = 0;
+    for (int j = 0; j < 16; ++j) {
+        const int64_t e = b * 16 + j;
+        if (e < U) {
+            const int64_t u = utt_order ? utt_order[e] : e;
+            sum += off[u + 1] - off[u];
+        }
+    }
+    base[b] = sum;
+}
+
+__global__ __launch_bounds__(1024) void fused_batch_scan_kernel(int64_t n_batches,
+                                                                int64_t* __restrict__ base) {
+    __shared__ int64_t part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (n_batches + 1023) / 1024;
+    const int64_t b0 = tid * per, b1 = b0 + per < n_batches ? b0 + per : n_batches;
+    int64_t sum = 0;
+    for (int64_t b = b0; b < b1; ++b) sum += base[b];
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int64_t v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int64_t run = part[tid] - sum;
+    for (int64_t b = b0; b < b1; ++b) {
+        const int64_t v = base[b];
+        base[b] = run;
+        run += v;
+    }
 }
 
 // Sum the replicas in fixed order, apply A to the xi accumulator.
@@ -377,15 +571,13 @@ __global__ void fused_finish_kernel(const double* __restrict__ replicas, srx_mod
     }
 }
 
-template <int R>
+template <int RQ, int H, int NTX>
 int launch(srx_context* h, const float* X, const int64_t* off, int64_t U, int64_t n_frames,
            const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* md,
-           FusedTables tb, float* lat, float* scale, double* replicas, int rec_size,
-           hipStream_t st) {
-    const int rec_pad = (rec_size + 1) & ~1;
-    const size_t wave_bytes = sizeof(double) * rec_pad + sizeof(float) * (3 * 256 + 16 * 8 * R);
-    const size_t lds = wave_bytes * kWavesPerBlock;
-    auto kern = estep_fused_kernel<R>;
+           FusedTables tb, const int64_t* batch_base, float* lat, float* scale, double* replicas,
+           int rec_size, hipStream_t st) {
+    const size_t lds = sizeof(float) * 2 * (3 * 256 + 16 * frame_tile_stride(16 * RQ + 8 * H)) * kWavesPerBlock;
+    auto kern = estep_fused_kernel<RQ, H, NTX>;
     SRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
     const int64_t n_groups = (U + 15) / 16;
@@ -395,7 +587,7 @@ int launch(srx_context* h, const float* X, const int64_t* off, int64_t U, int64_
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kWavesPerBlock), lds, st, X, off, U,
                        n_frames, utt_model, utt_order, md->n_models, md->n_states, md->n_features,
-                       tb, lat, scale, replicas, rec_size);
+                       tb, batch_base, lat, scale, replicas, rec_size);
     SRX_HIP(hipGetLastError());
     return SRX_OK;
 }
@@ -406,23 +598,23 @@ int srx_fused_estep(srx_context* h, const void* X, const int64_t* off, int64_t U
                     const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* md,
                     double* out_stats, hipStream_t st) {
     const int M = md->n_models, S = md->n_states, D = md->n_features;
-    if (S > 16 || D > 40 || n_frames <= 0 || U <= 0) return SRX_EUNSUPPORTED;
-    int R = (D + 7) / 8;
-    if (R == 3) R = 4;
-    if (R == 1) R = 2;
-    const int KQ = 4 * R;
+    if (S > 16 || D > 48 || n_frames <= 0 || U <= 0) return SRX_EUNSUPPORTED;
+    const int H = (D % 16 >= 1 && D % 16 <= 8) ? 1 : 0;
+    const int RQ = H ? D / 16 : (D + 15) / 16;
+    const int NTX = (2 * D + 15) / 16;
+    const int KW = 8 * RQ + 4 * H;
     const int rec_size = (int)srx_stats_layout(S, D).size;
-    const size_t n_w = (size_t)M * 16 * KQ * 4;
+    const size_t n_w = (size_t)M * 16 * KW * 4;
     float* base;
-    int rc = srx_ws_ensure(h, WS_PARAMS, sizeof(float) * (n_w + (size_t)M * 16 * 2 + (size_t)M * 256),
+    int rc = srx_ws_ensure(h, WS_PARAMS,
+                           sizeof(float) * (n_w + (size_t)M * 16 * 2 + (size_t)M * 256),
                            (void**)&base);
     if (rc) return rc;
     FusedTables tb;
-    float* W = base;
-    float* cst = W + n_w;
+    float* cst = base + n_w;
     float* A = cst + (size_t)M * 16;
     float* pi = A + (size_t)M * 256;
-    tb.W = W; tb.cst = cst; tb.A = A; tb.pi = pi;
+    tb.W = base; tb.cst = cst; tb.A = A; tb.pi = pi;
     float *lat, *scale;
     double* replicas;
     if ((rc = srx_ws_ensure(h, WS_LATTICE, sizeof(float) * (size_t)n_frames * 16, (void**)&lat))) return rc;
@@ -430,11 +622,23 @@ int srx_fused_estep(srx_context* h, const void* X, const int64_t* off, int64_t U
     const size_t rep_bytes = sizeof(double) * (size_t)kReplicas * M * rec_size;
     if ((rc = srx_ws_ensure(h, WS_PARTIAL, rep_bytes, (void**)&replicas))) return rc;
     SRX_HIP(hipMemsetAsync(replicas, 0, rep_bytes, st));
-    hipLaunchKernelGGL(fused_prep_kernel, dim3(8), dim3(256), 0, st, *md, R, W, cst, A, pi);
+    const int64_t n_batches = (U + 15) / 16;
+    int64_t* batch_base;
+    if ((rc = srx_ws_ensure(h, WS_MISC, sizeof(int64_t) * (size_t)n_batches, (void**)&batch_base))) return rc;
+    hipLaunchKernelGGL(fused_batch_total_kernel, dim3((unsigned)((n_batches + 255) / 256)), dim3(256),
+                       0, st, off, U, utt_order, n_batches, batch_base);
+    hipLaunchKernelGGL(fused_batch_scan_kernel, dim3(1), dim3(1024), 0, st, n_batches, batch_base);
+    hipLaunchKernelGGL(fused_prep_kernel, dim3(8), dim3(256), 0, st, *md, RQ, H, base, cst, A, pi);
     const float* Xf = (const float*)X;
-    if (R == 2) rc = launch<2>(h, Xf, off, U, n_frames, utt_model, utt_order, md, tb, lat, scale, replicas, rec_size, st);
-    else if (R == 4) rc = launch<4>(h, Xf, off, U, n_frames, utt_model, utt_order, md, tb, lat, scale, replicas, rec_size, st);
-    else rc = launch<5>(h, Xf, off, U, n_frames, utt_model, utt_order, md, tb, lat, scale, replicas, rec_size, st);
+#define SRX_CASE(rq, hh, ntx)                                                                \
+    if (RQ == rq && H == hh && NTX == ntx) {                                                  \
+        rc = launch<rq, hh, ntx>(h, Xf, off, U, n_frames, utt_model, utt_order, md, tb,       \
+                                 batch_base, lat, scale, replicas, rec_size, st);             \
+    } else
+    SRX_CASE(0, 1, 1) SRX_CASE(1, 0, 2) SRX_CASE(1, 1, 3) SRX_CASE(2, 0, 4) SRX_CASE(2, 1, 5)
+    SRX_CASE(3, 0, 6)
+    { return SRX_EUNSUPPORTED; }
+#undef SRX_CASE
     if (rc) return rc;
     hipLaunchKernelGGL(fused_finish_kernel, dim3(8), dim3(256), 0, st, (const double*)replicas, *md,
                        rec_size, out_stats);
