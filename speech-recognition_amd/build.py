@@ -12,6 +12,9 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsrx.so")
 SOURCES = ["api.hip", "hmm_generic.hip", "score_mfma.hip", "estep_fused.hip", "mfcc.hip", "mfcc_fast.hip"]
+# Packed f32 vector instructions (what SLP vectorisation makes of adjacent adds and
+# multiplies) issue slower than the two plain ones beside matrix instructions.
+FILE_FLAGS = {"score_mfma.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall",
          "-Wno-unused-function", "-fvisibility=default",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC]
@@ -43,7 +46,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [_hipcc()] + FLAGS + extra + ["-c", src, "-o", obj]
+            cmd = [_hipcc()] + FLAGS + FILE_FLAGS.get(s, []) + extra + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd)))

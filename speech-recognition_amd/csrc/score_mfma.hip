@@ -26,9 +26,6 @@
 #include <stdlib.h>
 #include <type_traits>
 
-#ifndef SRX_ABL
-#define SRX_ABL 0
-#endif
 
 namespace {
 
@@ -402,11 +399,16 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
         model[nt] = (nt * 16 + 4 * g) / SP;
     }
 
+    // alpha is kept UNNORMALISED: alpha_t = (A^T alpha_{t-1}) b~_t / c_{t-1}, with the
+    // division folded into the exponent of b~_t (shift = row maximum + log2 c_{t-1}),
+    // so c_t = sum(alpha_t) is the usual scale factor and costs no multiplies.
     f32x4 alpha[NT];
+    float lc[NT];          // log2 c_{t-1}; 0 for a dead chain (its alpha is all zero)
     double lp[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         lp[nt] = 0.0;
+        lc[nt] = 0.f;
         alpha[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
@@ -426,8 +428,11 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
 #pragma unroll
     for (int k = 0; k < PF; ++k) load(k, xq[k]);
 
-    // first: std::true_type for t == 0 (start probabilities instead of the transition product)
-    auto step = [&](auto first, int t, const u32x4 (&xc)[RQ]) {
+    // first: std::true_type for t == 0 (start probabilities instead of the transition
+    // product); ragged: std::false_type when every lane of the wave is known to be
+    // inside its utterance at step t (no selects); lpf: float partial sums of the
+    // log-probability, folded into the double by the caller.
+    auto step = [&](auto first, auto ragged, int t, const u32x4 (&xc)[RQ], float (&lpf)[NT]) {
         f32x4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = c0[nt];
@@ -483,8 +488,9 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             f32x4 b;
+            const float sh = decltype(first)::value ? mx[nt] : mx[nt] + lc[nt];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) b[r] = __builtin_amdgcn_exp2f(acc[nt][r] - mx[nt]);
+            for (int r = 0; r < 4; ++r) b[r] = __builtin_amdgcn_exp2f(acc[nt][r] - sh);
             if constexpr (decltype(first)::value) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -507,30 +513,69 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            // alpha is the next step's matrix operand for EVERY row of this
-            // utterance's column: a dead chain (c == 0: padding rows of the tile, or
-            // a sequence the model cannot emit) must feed zeros, not NaN, or it
-            // would poison the other model of the tile.  Its own log-probability
-            // stays -inf / NaN as in the reference.
-            const float ci = c[nt] > 0.f ? __builtin_amdgcn_rcpf(c[nt]) : 0.f;
-            const double dl = (double)(mx[nt] + __builtin_amdgcn_logf(c[nt]));
-            lp[nt] += live ? dl : 0.0;
+            // A dead chain (c == 0: padding rows of the tile, or a sequence the
+            // model cannot emit) has alpha == 0 from here on; its shift stays finite
+            // so that the other model of the tile never meets inf or NaN.  Its own
+            // log-probability becomes -inf as in the reference.
+            const float l2 = __builtin_amdgcn_logf(c[nt]);
+            const float lcn = c[nt] > 0.f ? l2 : 0.f;
+            if constexpr (decltype(ragged)::value) {
+                lpf[nt] += live ? mx[nt] + l2 : 0.f;
+                lc[nt] = live ? lcn : lc[nt];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) alpha[nt][r] = live ? na[nt][r] * ci : alpha[nt][r];
+                for (int r = 0; r < 4; ++r) alpha[nt][r] = live ? na[nt][r] : alpha[nt][r];
+            } else {
+                lpf[nt] += mx[nt] + l2;
+                lc[nt] = lcn;
+                alpha[nt] = na[nt];
+            }
+        }
+    };
+    auto fold = [&](float (&lpf)[NT]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            lp[nt] += (double)lpf[nt];
+            lpf[nt] = 0.f;
         }
     };
 
-    // t = 0, then groups of PF steps with static queue slots (slot = t mod PF)
+    // t = 0, then groups of PF steps with static queue slots (slot = t mod PF):
+    // first the groups every lane is live in, then the ragged tail.
+    int Tmin = T;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) Tmin = min(Tmin, __shfl_xor(Tmin, o, 64));
+    float lpf[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) lpf[nt] = 0.f;
     if (Tmax > 0) {
-        step(std::true_type{}, 0, xq[0]);
+        step(std::true_type{}, std::true_type{}, 0, xq[0], lpf);
+        fold(lpf);
         load(PF, xq[0]);
     }
-    for (int t0 = 1; t0 < Tmax; t0 += PF) {
+    int t0 = 1;
+    for (; t0 + PF <= Tmin; t0 += PF) {
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
-            step(std::false_type{}, t0 + k, xq[(1 + k) % PF]);
+            step(std::false_type{}, std::false_type{}, t0 + k, xq[(1 + k) % PF], lpf);
             load(t0 + k + PF, xq[(1 + k) % PF]);
         }
+        fold(lpf);
+        // Scheduling request for this loop body: one matrix instruction, then four
+        // vector instructions, repeated.  The matrix pipe runs beside the vector
+        // pipe only where the stream alternates between them.
+#pragma unroll
+        for (int i = 0; i < PF * (RQ * 3 * NT + 4 * NT); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+    }
+    for (; t0 < Tmax; t0 += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            step(std::false_type{}, std::true_type{}, t0 + k, xq[(1 + k) % PF], lpf);
+            load(t0 + k + PF, xq[(1 + k) % PF]);
+        }
+        fold(lpf);
     }
 
     if (valid) {
