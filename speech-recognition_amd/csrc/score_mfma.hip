@@ -589,6 +589,123 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Stand-alone emission log-densities (all states of all models, natural log),
+// float32: frames are the MFMA columns here -- a wave takes 16 CONSECUTIVE frames
+// (one contiguous 16 D-float piece of X), NTC tiles of 16 state columns, and
+// writes out[frame][column].  Same split-bf16 contraction as the scoring kernel.
+__device__ __forceinline__ void split_operand(const u32x4& xc, bf16x8& bh, bf16x8& bl) {
+    float x[4], sq[4];
+    unsigned xl_[2], sl_[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        x[j] = __uint_as_float(xc[j]);
+        sq[j] = x[j] * x[j];
+    }
+    u32x4 fh;
+    fh[0] = __builtin_amdgcn_perm(xc[1], xc[0], 0x07060302u);
+    fh[1] = __builtin_amdgcn_perm(xc[3], xc[2], 0x07060302u);
+    fh[2] = __builtin_amdgcn_perm(__float_as_uint(sq[1]), __float_as_uint(sq[0]), 0x07060302u);
+    fh[3] = __builtin_amdgcn_perm(__float_as_uint(sq[3]), __float_as_uint(sq[2]), 0x07060302u);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const bf16x2 a = {(__bf16)(x[2 * j] - __uint_as_float(xc[2 * j] & 0xffff0000u)),
+                          (__bf16)(x[2 * j + 1] - __uint_as_float(xc[2 * j + 1] & 0xffff0000u))};
+        const bf16x2 b = {
+            (__bf16)(sq[2 * j] - __uint_as_float(__float_as_uint(sq[2 * j]) & 0xffff0000u)),
+            (__bf16)(sq[2 * j + 1] - __uint_as_float(__float_as_uint(sq[2 * j + 1]) & 0xffff0000u))};
+        xl_[j] = __builtin_bit_cast(unsigned, a);
+        sl_[j] = __builtin_bit_cast(unsigned, b);
+    }
+    const u32x4 fl = {xl_[0], xl_[1], sl_[0], sl_[1]};
+    bh = __builtin_bit_cast(bf16x8, fh);
+    bl = __builtin_bit_cast(bf16x8, fl);
+}
+
+template <int NTC, int RQ>
+__global__ __launch_bounds__(256) void emission_split_kernel(
+    const float* __restrict__ X, int64_t n_frames, int C, int D, int NT, SplitTables tb,
+    float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, ul = lane & 15;
+    const int nt0 = blockIdx.y * NTC;
+    u32x4 wh[NTC][RQ], wl[NTC][RQ];
+    f32x4 c0[NTC];
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt) {
+        const bool on = nt0 + nt < NT;
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) {
+            const unsigned* p = tb.Wp + ((((size_t)((on ? nt0 + nt : 0) * 16 + ul)) * RQ + q) * 2 * 4 + g) * 4;
+            wh[nt][q] = on ? *(const u32x4*)p : u32x4{0u, 0u, 0u, 0u};
+            wl[nt][q] = on ? *(const u32x4*)(p + 16) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c0[nt][r] = on ? tb.cst[(nt0 + nt) * 16 + 4 * g + r] : 0.f;
+    }
+    const int64_t n_groups = (n_frames + 15) / 16;
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const unsigned lane_off = (unsigned)ul * (unsigned)D * 4u + 16u * g;
+    auto load = [&](int64_t grp, u32x4 (&dst)[RQ]) {
+        // descriptor over [first frame of the group, end of X): frames past the
+        // end read zeros
+        const int64_t f0 = grp < n_groups ? grp * 16 : 0;
+        const int64_t rest = grp < n_groups ? (n_frames - f0) * (int64_t)D * 4 : 0;
+        const uintptr_t a = (uintptr_t)(X + f0 * D);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        const unsigned n = (unsigned)(rest < 0xFFFFFF00ll ? rest : 0xFFFFFF00ll);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
+#pragma unroll
+        for (int q = 0; q < RQ; ++q)
+            dst[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off + 64u * q, 0, 0);
+    };
+    u32x4 xa[RQ], xb[RQ];
+    load(wid, xa);
+    for (int64_t grp = wid; grp < n_groups; grp += n_waves) {
+        load(grp + n_waves, xb);
+        f32x4 acc[NTC];
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) acc[nt] = c0[nt];
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) {
+            bf16x8 bh, bl;
+            split_operand(xa[q], bh, bl);
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wh[nt][q]), bh, acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wh[nt][q]), bl, acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wl[nt][q]), bh, acc[nt], 0, 0, 0);
+        }
+        const int64_t f = grp * 16 + ul;
+        if (f < n_frames) {
+            float* o = out + f * C;
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt) {
+                const int col = (nt0 + nt) * 16 + 4 * g;
+                const f32x4 v = acc[nt] * (float)kLn2;
+                if ((C & 3) == 0 && col + 3 < C) {
+                    *(f32x4*)(o + col) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col + r < C) o[col + r] = v[r];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) xa[q] = xb[q];
+    }
+}
+
 template <int SP, int NT, int RQ>
 void launch_split(const float* X, const int64_t* off, int64_t U, int64_t n_frames, int M, int S,
                   int D, SplitTables tb, double* out, hipStream_t st) {
@@ -608,6 +725,45 @@ void launch(const float* X, const int64_t* off, int64_t U, int64_t n_frames, int
 }
 
 }  // namespace
+
+int srx_mfma_emission(srx_context* h, const void* X, int64_t n_frames, const srx_models_t* md,
+                      float* out, hipStream_t st) {
+    const int M = md->n_models, S = md->n_states, D = md->n_features;
+    const int64_t C64 = (int64_t)M * S;
+    if (h->exact_f32 || D > 48 || n_frames <= 0 || C64 > 4096) return SRX_EUNSUPPORTED;
+    const int C = (int)C64, NT = (C + 15) / 16, RQ = (D + 15) / 16;
+    const size_t n_wp = (size_t)NT * 16 * RQ * 2 * 4 * 4, n_c = (size_t)NT * 16;
+    unsigned* base;
+    int rc = srx_ws_ensure(h, WS_PARAMS, 4 * (n_wp + n_c + (size_t)M * S * S + (size_t)M * S),
+                           (void**)&base);
+    if (rc) return rc;
+    SplitTables tb;
+    float* cst = (float*)(base + n_wp);
+    float* A = cst + n_c;
+    float* pi = A + (size_t)M * S * S;
+    tb.Wp = base; tb.cst = cst; tb.A = A; tb.pi = pi;
+    // rows of the table = columns of the output: "padded states per model" = S
+    hipLaunchKernelGGL(split_prep_kernel, dim3(8), dim3(256), 0, st, *md, S, NT, RQ, base, cst, A, pi);
+    const int NTC = NT >= 3 ? 3 : NT;
+    const int chunks = (NT + NTC - 1) / NTC;
+    const int64_t n_groups = (n_frames + 15) / 16;
+    int64_t gx = (n_groups + 3) / 4;
+    const int64_t cap = (int64_t)h->n_cu * 8;
+    if (gx > cap) gx = cap;
+    const dim3 grid((unsigned)gx, (unsigned)chunks);
+    const float* Xf = (const float*)X;
+#define SRX_CASE(ntc, rq)                                                                    \
+    if (NTC == ntc && RQ == rq) {                                                            \
+        hipLaunchKernelGGL((emission_split_kernel<ntc, rq>), grid, dim3(256), 0, st, Xf,     \
+                           n_frames, C, D, NT, tb, out);                                     \
+        SRX_HIP(hipGetLastError());                                                          \
+        return SRX_OK;                                                                       \
+    }
+    SRX_CASE(3, 3) SRX_CASE(3, 2) SRX_CASE(3, 1) SRX_CASE(2, 3) SRX_CASE(2, 2) SRX_CASE(2, 1)
+    SRX_CASE(1, 3) SRX_CASE(1, 2) SRX_CASE(1, 1)
+#undef SRX_CASE
+    return SRX_EUNSUPPORTED;
+}
 
 int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
                    const srx_models_t* md, double* out, hipStream_t st) {

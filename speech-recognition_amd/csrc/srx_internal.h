@@ -101,6 +101,10 @@ int srx_generic_mstep(srx_context* h, const double* stats, const srx_priors_t* p
 
 // Implemented in score_mfma.hip: returns SRX_EUNSUPPORTED when the shape has no
 // matrix-core kernel, so the caller can take the generic path.
+// float32 emission log-densities on the matrix cores (split-bf16); SRX_EUNSUPPORTED
+// when the shape or the exact-f32 option rules it out.
+int srx_mfma_emission(srx_context* h, const void* X, int64_t n_frames, const srx_models_t* md,
+                      float* out, hipStream_t st);
 int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
                    int64_t n_frames, const srx_models_t* models, double* out,
                    hipStream_t st);

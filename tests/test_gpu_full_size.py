@@ -1,0 +1,135 @@
+"""The hot path at the benchmark's full sizes, checked through properties that do
+not need the oracle to run the whole workload:
+
+* scoring 65,536 x 200 x 39 against 6 x 8 states: a random sample of utterances
+  agrees with the numpy oracle; permuting the utterances permutes the scores
+  bit for bit; the matrix-core kernel agrees with the shape-generic kernel;
+* Baum-Welch statistics of 32,768 x 200 x 39 with 6 x 16 states: the counting
+  identities of the statistics record hold (sum of posteriors = frames,
+  start counts = utterances, transition counts = frames - utterances, obs sums
+  consistent with posteriors), a sample of the per-model sums agrees with the
+  oracle run on that model's utterances of a small prefix, and two ranks' worth
+  of shards add up to the whole (the data-parallel identity).
+
+Tolerances are the float32 ones of the parity tests (1e-4 relative on
+log-likelihoods, 2e-5 on statistics)."""
+import numpy as np
+import pytest
+
+from oracle import hmm_oracle as ho
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sra():
+    import speech_recognition_amd as s
+    return s
+
+
+@pytest.fixture(scope="module")
+def ctx(sra):
+    return sra.Context.default()
+
+
+def _models(rng, M, S, D):
+    prms = [ho.random_params(rng, S, D) for _ in range(M)]
+    return prms
+
+
+def _bank(sra, ctx, prms):
+    return sra.HMMBank(ctx, np.stack([p.pi for p in prms]), np.stack([p.A for p in prms]),
+                       np.stack([p.means for p in prms]), np.stack([p.covars for p in prms]))
+
+
+def test_scoring_full_size_properties(sra, ctx):
+    import torch
+    U, T, D, M, S = 65536, 200, 39, 6, 8
+    rng = np.random.default_rng(2024)
+    prms = _models(rng, M, S, D)
+    bank = _bank(sra, ctx, prms)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    X = torch.randn((U * T, D), device="cuda", dtype=torch.float32, generator=g)
+    off = torch.arange(0, (U + 1) * T, T, device="cuda", dtype=torch.int64)
+    data = sra.Ragged(ctx, X, offsets=off, dtype="float32")
+    sc = bank.score(data).clone()
+    assert sc.shape == (U, M) and bool(torch.isfinite(sc).all())
+    # (1) a sample against the oracle
+    pick = rng.choice(U, size=24, replace=False)
+    for u in pick:
+        xu = X[u * T:(u + 1) * T].cpu().numpy().astype(np.float64)
+        ref = np.array([ho.score(p, xu, [T], loops=False)[0] for p in prms])
+        got = sc[u].cpu().numpy()
+        assert np.max(np.abs(got - ref) / np.abs(ref)) < 2e-5
+    # (2) permuting utterances permutes scores, bit for bit
+    perm = torch.randperm(U, device="cuda", generator=g)
+    Xp = X.view(U, T, D)[perm].reshape(U * T, D).contiguous()
+    scp = bank.score(sra.Ragged(ctx, Xp, offsets=off, dtype="float32"))
+    assert torch.equal(scp, sc[perm])
+    del Xp
+    # (3) matrix-core kernel against the shape-generic kernel on a slice
+    n = 2048
+    part = sra.Ragged(ctx, X[:n * T], offsets=off[:n + 1], dtype="float32")
+    a = bank.score(part).cpu().numpy()
+    b = bank.score(part, generic=True).cpu().numpy()
+    assert np.max(np.abs(a - b) / np.abs(b)) < 2e-5
+    assert np.array_equal(a, sc[:n].cpu().numpy())          # batch position does not matter
+
+
+def test_estep_full_size_identities(sra, ctx):
+    import torch
+    U, T, D, M, S = 32768, 200, 39, 6, 16
+    rng = np.random.default_rng(77)
+    prms = _models(rng, M, S, D)
+    bank = _bank(sra, ctx, prms)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    X = torch.randn((U * T, D), device="cuda", dtype=torch.float32, generator=g)
+    lengths = rng.integers(150, T + 1, size=U)               # ragged inside fixed slots
+    starts = np.arange(U, dtype=np.int64) * T
+    # pack the ragged utterances: keep the first lengths[u] frames of every slot
+    keep = torch.from_numpy(np.concatenate([np.arange(s, s + n) for s, n in zip(starts, lengths)])).cuda()
+    Xr = X[keep].contiguous()
+    del X, keep
+    data = sra.Ragged(ctx, Xr, lengths, dtype="float32")
+    um = (np.arange(U) % M).astype(np.int32)
+    tr = sra.parallel.BaumWelchTrainer(bank, data, um)
+    tr.bank.estep(tr.data, tr.utt_model, tr.utt_order, out=tr.stats)
+    st = bank.unpack_stats(tr.stats)
+    n_frames = np.array([lengths[um == m].sum() for m in range(M)], dtype=np.float64)
+    n_utts = np.array([(um == m).sum() for m in range(M)], dtype=np.float64)
+    for m in range(M):
+        s = st[m]
+        assert s["nobs"] == n_utts[m]
+        assert np.isfinite(s["logprob"])
+        assert abs(s["post"].sum() - n_frames[m]) < 2e-5 * n_frames[m]
+        assert abs(s["start"].sum() - n_utts[m]) < 2e-5 * n_utts[m]
+        assert abs(s["trans"].sum() - (n_frames[m] - n_utts[m])) < 2e-5 * n_frames[m]
+        # rows of the xi sums: out-flow of state i = its posterior mass minus last frames
+        assert np.all(s["trans"].sum(axis=1) <= s["post"] * (1 + 1e-4) + 1e-3)
+        # weighted second moments dominate squared first moments (Cauchy-Schwarz)
+        assert np.all(s["obs**2"] * s["post"][:, None] >= s["obs"] ** 2 * (1 - 1e-4) - 1e-3)
+    # a prefix against the oracle: the first 96 utterances on their own
+    n = 96
+    offs = np.concatenate([[0], np.cumsum(lengths[:n])])
+    Xs = Xr[:offs[-1]].cpu().numpy().astype(np.float64)
+    small = sra.Ragged(ctx, Xr[:offs[-1]], lengths[:n], dtype="float32")
+    got = bank.unpack_stats(bank.estep(small, ctx.tensor(um[:n]), None))
+    for m in range(M):
+        sel = [u for u in range(n) if um[u] == m]
+        Xm = np.vstack([Xs[offs[u]:offs[u + 1]] for u in sel])
+        ref, lps = ho.estep(prms[m], Xm, [int(lengths[u]) for u in sel], loops=False)
+        np.testing.assert_allclose(got[m]["logprob"], lps.sum(), rtol=1e-5)
+        for k in ("start", "trans", "post", "obs", "obs**2"):
+            np.testing.assert_allclose(got[m][k], ref[k], rtol=2e-5,
+                                       atol=2e-5 * max(1.0, np.abs(ref[k]).max()))
+    # data-parallel identity: two shards' statistics add up to the whole
+    lo, hi = sra.parallel.shard_utterances(lengths, 0, 2), sra.parallel.shard_utterances(lengths, 1, 2)
+    total = np.zeros_like(tr.stats.cpu().numpy())
+    off_all = np.concatenate([[0], np.cumsum(lengths)])
+    for a, b in (lo, hi):
+        shard = sra.Ragged(ctx, Xr[off_all[a]:off_all[b]], lengths[a:b], dtype="float32")
+        total += bank.estep(shard, ctx.tensor(um[a:b]), None).cpu().numpy()
+    whole = tr.stats.cpu().numpy()
+    np.testing.assert_allclose(total, whole, rtol=2e-6, atol=2e-6 * np.abs(whole).max())

@@ -1,0 +1,32 @@
+"""Time the stand-alone emission log-likelihood: python tools/emission_bench.py [M] [S] [frames] [D]."""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import speech_recognition_amd as sra
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+F = int(sys.argv[3]) if len(sys.argv) > 3 else 65536 * 200
+D = int(sys.argv[4]) if len(sys.argv) > 4 else 39
+ctx = sra.Context.default(0)
+X = torch.randn((F, D), device='cuda', dtype=torch.float32)
+data = sra.Ragged(ctx, X, [F], dtype="float32")
+rng = np.random.default_rng(8)
+bank = sra.HMMBank(ctx, rng.dirichlet(np.ones(S), size=M), rng.dirichlet(np.ones(S), size=(M, S)),
+                   rng.standard_normal((M, S, D)), rng.uniform(0.5, 1.5, (M, S, D)))
+ll = bank.emission_loglik(data)
+torch.cuda.synchronize()
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+n = 10
+ev0.record()
+for _ in range(n):
+    ll = bank.emission_loglik(data)
+ev1.record()
+torch.cuda.synchronize()
+ms = ev0.elapsed_time(ev1) / n
+byt = F * (D * 4 + M * S * 4)
+# spot check against float64 numpy on 64 frames
+idx = torch.randint(0, F, (64,), device='cuda')
+x = X[idx].double().cpu().numpy()
+sp, A, mu, cv = bank.params_host()
+ref = -0.5 * (np.log(2 * np.pi * cv).sum(-1)[None] + (((x[:, None, None, :] - mu[None]) ** 2) / cv[None]).sum(-1))
+err = np.abs(ll[idx].cpu().numpy().reshape(64, M, S) - ref).max() / np.abs(ref).max()
+print(f"M={M} S={S} F={F} D={D}: {ms:.4f} ms  {F/ms/1e6:.2f} Gframes/s  {byt/ms/1e9:.3f} TB/s (in+out)  max rel err {err:.2e}")
