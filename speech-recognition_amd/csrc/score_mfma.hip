@@ -321,19 +321,23 @@ __global__ void split_prep_kernel(srx_models_t md, int SP, int NT, int RQ, unsig
         }
         for (int k = 0; k < 4; ++k) Wp[(size_t)i * 4 + k] = (unsigned)v[2 * k] | ((unsigned)v[2 * k + 1] << 16);
     }
-    for (int row = tid; row < NT * 16; row += nth) {
+    // constants: one wave per row, lanes over features (the serial sum of D
+    // logarithms per row would be most of this kernel's time)
+    const int wave = tid >> 6, lane = tid & 63, n_wave = nth >> 6;
+    for (int row = wave; row < NT * 16; row += n_wave) {
         const int m = row / SP, s = row % SP;
-        float v = kNegBig;
-        if (m < M && s < S) {
-            double acc = D * 1.8378770664093453;
-            for (int d = 0; d < D; ++d) {
+        const bool on = m < M && s < S;
+        double acc = 0.0;
+        if (on)
+            for (int d = lane; d < D; d += 64) {
                 const size_t k = ((size_t)m * S + s) * D + d;
                 const double var = fmax(md.covars[k], 2.2250738585072014e-308);
                 acc += log(var) + md.means[k] * md.means[k] / var;
             }
-            v = (float)(-0.5 * acc * 1.4426950408889634);
-        }
-        cst[row] = v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0)
+            cst[row] = on ? (float)(-0.5 * (acc + D * 1.8378770664093453) * 1.4426950408889634) : kNegBig;
     }
     for (int i = tid; i < M * S * S; i += nth) A[i] = (float)md.transmat[i];
     for (int i = tid; i < M * S; i += nth) pi[i] = (float)md.startprob[i];
@@ -743,7 +747,7 @@ int srx_mfma_emission(srx_context* h, const void* X, int64_t n_frames, const srx
     float* pi = A + (size_t)M * S * S;
     tb.Wp = base; tb.cst = cst; tb.A = A; tb.pi = pi;
     // rows of the table = columns of the output: "padded states per model" = S
-    hipLaunchKernelGGL(split_prep_kernel, dim3(8), dim3(256), 0, st, *md, S, NT, RQ, base, cst, A, pi);
+    hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, S, NT, RQ, base, cst, A, pi);
     const int NTC = NT >= 3 ? 3 : NT;
     const int chunks = (NT + NTC - 1) / NTC;
     const int64_t n_groups = (n_frames + 15) / 16;
@@ -788,7 +792,7 @@ int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
         float* A = cst + n_c;
         float* pi = A + (size_t)M * S * S;
         tb.Wp = base; tb.cst = cst; tb.A = A; tb.pi = pi;
-        hipLaunchKernelGGL(split_prep_kernel, dim3(8), dim3(256), 0, st, *md, SP, NT, RQ, base, cst,
+        hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, SP, NT, RQ, base, cst,
                            A, pi);
         const float* Xf = (const float*)X;
 #define SRX_CASE(sp, nt, rq)                                                       \
