@@ -160,6 +160,33 @@ def main():
     # ------------------------------------------------------------------ extras
     if not args.no_extra:
         extra = {}
+        # stand-alone emission log-likelihoods and Viterbi decoding on the scoring batch
+        ll = bank.emission_loglik(data)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ll = bank.emission_loglik(data)
+        barrier()
+        dte = (time.perf_counter() - t0) / 3
+        n_fr = U * T_FRAMES
+        extra["emission"] = {"frames_per_s": n_fr * world / dte, "ms": dte * 1e3,
+                             "hbm_frac": n_fr * (N_FEAT + N_MODELS * N_STATES) * 4 / dte / 1e9 / HBM_PEAK_GBS,
+                             "config": "log-densities of 48 state columns, float32 in and out "
+                                       "(156 B in + 192 B out per frame)"}
+        del ll
+        um = ctx.tensor((np.arange(U) % N_MODELS).astype(np.int32))
+        vlp, vpath = bank.viterbi(data, um)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            vlp, vpath = bank.viterbi(data, um)
+        barrier()
+        dtv = (time.perf_counter() - t0) / 3
+        extra["viterbi"] = {"frames_per_s": n_fr * world / dtv, "ms": dtv * 1e3,
+                            "hbm_frac": n_fr * (N_FEAT * 4 + 4) / dtv / 1e9 / HBM_PEAK_GBS,
+                            "config": "one 8-state model per utterance (u mod 6), int32 path out "
+                                      "(156 B in + 4 B out per frame)"}
+        del vlp, vpath, um
         del X, data
         torch.cuda.empty_cache()
         # front-end: 16 kHz, 25/10 ms, 512-pt FFT, 40 mel, 13 ceps + delta + delta-delta

@@ -19,6 +19,8 @@
 // and log P = sum_t (m_t - log c~_t), so nothing underflows in float.
 #include "srx_internal.h"
 
+#include <type_traits>
+
 #include <math.h>
 
 __global__ void srx_fill_slices(int64_t* offs, int64_t n_slices, int64_t slice, int64_t n_frames);
@@ -577,8 +579,16 @@ int viterbi_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int6
     if (rc) return rc;
     rc = srx_ws_ensure(h, WS_BACKPTR, (size_t)n_frames * S, (void**)&bp);
     if (rc) return rc;
-    hipLaunchKernelGGL(emission_kernel<T>, dim3(grid_for(h, U, 1)), dim3(kBlock), 0, st,
-                       (const T*)X, off, U, utt_model, 0, M, S, D, tb, ll);
+    bool done = false;
+    if constexpr (std::is_same<T, float>::value) {
+        // matrix-core emission where the shape allows it
+        rc = srx_mfma_emission_utt(h, X, off, U, n_frames, utt_model, md, (float*)ll, st);
+        if (rc == SRX_OK) done = true;
+        else if (rc != SRX_EUNSUPPORTED) return rc;
+    }
+    if (!done)
+        hipLaunchKernelGGL(emission_kernel<T>, dim3(grid_for(h, U, 1)), dim3(kBlock), 0, st,
+                           (const T*)X, off, U, utt_model, 0, M, S, D, tb, ll);
     const int sp = sub_width(S);
     SP_DISPATCH(sp, hipLaunchKernelGGL((viterbi_chain_kernel<T, SP>),
                                        dim3(grid_for(h, U, kBlock / SP)), dim3(kBlock), 0, st,

@@ -105,6 +105,11 @@ int srx_generic_mstep(srx_context* h, const double* stats, const srx_priors_t* p
 // when the shape or the exact-f32 option rules it out.
 int srx_mfma_emission(srx_context* h, const void* X, int64_t n_frames, const srx_models_t* md,
                       float* out, hipStream_t st);
+// The same for each utterance's own model only: out[frame][state] (S <= 16).  Its
+// tables live in the WS_MISC slot.
+int srx_mfma_emission_utt(srx_context* h, const void* X, const int64_t* off, int64_t U,
+                          int64_t n_frames, const int32_t* utt_model, const srx_models_t* md,
+                          float* out, hipStream_t st);
 int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
                    int64_t n_frames, const srx_models_t* models, double* out,
                    hipStream_t st);

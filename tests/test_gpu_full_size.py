@@ -133,3 +133,33 @@ def test_estep_full_size_identities(sra, ctx):
         total += bank.estep(shard, ctx.tensor(um[a:b]), None).cpu().numpy()
     whole = tr.stats.cpu().numpy()
     np.testing.assert_allclose(total, whole, rtol=2e-6, atol=2e-6 * np.abs(whole).max())
+
+
+def test_viterbi_full_size_properties(sra, ctx):
+    """65,536 x 200 x 39, one 8-state model per utterance: the best path can not
+    beat the sum over paths; a sample of utterances agrees with the oracle (a
+    differing frame must be a near-tie: the path's own log-probability then agrees)."""
+    import torch
+    U, T, D, M, S = 65536, 200, 39, 6, 8
+    rng = np.random.default_rng(31)
+    prms = _models(rng, M, S, D)
+    bank = _bank(sra, ctx, prms)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    X = torch.randn((U * T, D), device="cuda", dtype=torch.float32, generator=g)
+    off = torch.arange(0, (U + 1) * T, T, device="cuda", dtype=torch.int64)
+    data = sra.Ragged(ctx, X, offsets=off, dtype="float32")
+    um = (np.arange(U) % M).astype(np.int32)
+    lp, path = bank.viterbi(data, ctx.tensor(um))
+    sc = bank.score(data)
+    own = sc[torch.arange(U, device="cuda"), torch.from_numpy(um.astype(np.int64)).cuda()]
+    assert bool(torch.isfinite(lp).all())
+    assert bool((lp <= own + 1e-6 * own.abs()).all())
+    assert int(path.min()) >= 0 and int(path.max()) < S
+    pick = rng.choice(U, size=16, replace=False)
+    for u in pick:
+        xu = X[u * T:(u + 1) * T].cpu().numpy().astype(np.float64)
+        rlp, rpath = ho.viterbi(prms[um[u]], xu, [T])
+        got = path[u * T:(u + 1) * T].cpu().numpy()
+        assert abs(float(lp[u]) - rlp[0]) < 1e-5 * abs(rlp[0])
+        assert np.mean(got == rpath) > 0.97
