@@ -204,16 +204,23 @@ __global__ void finish_kernel(const T* __restrict__ cep, const int64_t* __restri
         const int TK = (int)(Tu * K);
         if (in_lds) {
             for (int i = threadIdx.x; i < TK; i += blockDim.x) blk[i] = cu[i];
+            // thread -> (coefficient k, row group r): no division in the loops
+            const int gk = blockDim.x / K, k = threadIdx.x % K, r = threadIdx.x / K;
+            const int Ti = (int)Tu;
             for (int o = 1; o <= order; ++o) {
                 __syncthreads();
-                const T* src = blk + (size_t)(o - 1) * TK;
-                T* dst = blk + (size_t)o * TK;
-                for (int i = threadIdx.x; i < TK; i += blockDim.x) {
-                    const int t = i / K, k = i % K;
-                    T acc = 0;
-                    for (int j = -N; j <= N; ++j) acc += (T)j * src[(int)clamp_t(t + j, Tu) * K + k];
-                    dst[i] = acc * inv_den;
-                }
+                const T* src = blk + (size_t)(o - 1) * TK + k;
+                T* dst = blk + (size_t)o * TK + k;
+                if (r < gk)
+                    for (int t = r; t < Ti; t += gk) {
+                        T acc = 0;
+                        for (int j = -N; j <= N; ++j) {
+                            int tt = t + j;
+                            tt = tt < 0 ? 0 : (tt >= Ti ? Ti - 1 : tt);
+                            acc += (T)j * src[tt * K];
+                        }
+                        dst[t * K] = acc * inv_den;
+                    }
             }
             __syncthreads();
         } else {
@@ -265,11 +272,21 @@ __global__ void finish_kernel(const T* __restrict__ cep, const int64_t* __restri
             col_scale[threadIdx.x] = (T)1;
         }
         __syncthreads();
-        if (in_lds || zscore)
+        if (in_lds) {
+            const int groups = blockDim.x / NF;
+            const int f = threadIdx.x % NF, r = threadIdx.x / NF;
+            if (r < groups) {
+                const T* src = blk + (size_t)(f / K) * TK + (size_t)trim * K + f % K;
+                const T mean = col_mean[f], inv = (T)1 / col_scale[f];
+                const int Tn = (int)To;
+                for (int t = r; t < Tn; t += groups) ou[(int64_t)t * NF + f] = (src[t * K] - mean) * inv;
+            }
+        } else if (zscore) {
             for (int64_t idx = threadIdx.x; idx < To * NF; idx += blockDim.x) {
                 const int ff = (int)(idx % NF);
-                ou[idx] = (feat(idx / NF, ff) - col_mean[ff]) / col_scale[ff];
+                ou[idx] = (ou[idx] - col_mean[ff]) / col_scale[ff];
             }
+        }
         __syncthreads();
     }
 }

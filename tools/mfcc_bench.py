@@ -1,5 +1,5 @@
-import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import speech_recognition_amd as sra
 ctx = sra.Context.default(0)
 n_utt, n_samp = 8192, 48000
