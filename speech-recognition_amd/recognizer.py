@@ -137,3 +137,69 @@ def test_trained_model(models, directory, sample_rate, folds_dir="Folds", lists=
 
 
 test_trained_model.__test__ = False   # not a pytest test
+
+
+def cross_validate(feats, lengths, names, folds, words=None, *, n_components=3, n_iter=8,
+                   init_fn=None, mstep="full", dtype="float64", ctx=None, random_state=0):
+    """The k-fold experiment of HMM_final.py:93-114 / :134-165 as ONE batched job:
+    a word model per (fold, word) -- 30 for the reference's 5 folds x 6 words --
+    all trained together (one E-step launch per EM iteration over every fold's
+    training utterances), then every fold's validation utterances scored against
+    that fold's models in one launch.
+
+    feats (sum T, D) packed features of all recordings, lengths (n,), names (n,)
+    recording names ``<word>_<k>``; folds: list of (train_names, validation_names).
+    init_fn(X_word, n_components) -> (startprob, transmat, means, covars) gives
+    each model's start (default: the class's ``init``, seeded per model).
+    Returns a dict with per-fold ``pred``, ``right``, ``scores`` (n_val, n_words)
+    and ``hist`` (n_folds, n_words, n_iter) log-likelihood histories, ``bank``."""
+    from .parallel import BaumWelchTrainer
+    ctx = ctx or Context.default()
+    names = [str(n) for n in names]
+    lengths = np.asarray(lengths, dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    index = {n: i for i, n in enumerate(names)}
+    words = list(words) if words is not None else sorted({_word_of(n) for n in names})
+    W, F = len(words), len(folds)
+    feats = np.asarray(feats)
+
+    def utt(n):
+        i = index[str(n).replace(".wav", "")]
+        return feats[off[i]:off[i + 1]]
+
+    inits, xs, um = [], [], []
+    for f, (train, _) in enumerate(folds):
+        for w_i, w in enumerate(words):
+            sel = [n for n in train if _word_of(str(n)) == w]
+            if not sel:
+                raise ValueError(f"fold {f + 1} has no training recording of {w!r}")
+            Xw = np.vstack([utt(n) for n in sel]).astype(np.float64)
+            if init_fn is not None:
+                inits.append(tuple(np.asarray(a, dtype=np.float64) for a in init_fn(Xw, n_components)))
+            else:
+                m = MyGaussianHMM(n_components=n_components, verbose=False,
+                                  random_state=random_state + f * W + w_i)
+                m.init(Xw, [len(utt(n)) for n in sel])
+                inits.append((m.startprob_, m.transmat_, m.means_, m._covars_))
+            xs += [utt(n) for n in sel]
+            um += [f * W + w_i] * len(sel)
+    bank = HMMBank(ctx, np.stack([i[0] for i in inits]), np.stack([i[1] for i in inits]),
+                   np.stack([i[2] for i in inits]), np.stack([i[3] for i in inits]))
+    data = Ragged(ctx, np.vstack(xs), [len(x) for x in xs], dtype=dtype)
+    trainer = BaumWelchTrainer(bank, data, np.asarray(um, dtype=np.int32), mstep=mstep)
+    hist = np.stack([trainer.step().cpu().numpy() for _ in range(n_iter)], axis=1)
+    vx, vfold = [], []
+    for f, (_, val) in enumerate(folds):
+        vx += [utt(n) for n in val]
+        vfold += [f] * len(val)
+    vdata = Ragged(ctx, np.vstack(vx), [len(x) for x in vx], dtype=dtype)
+    all_scores = bank.score(vdata).cpu().numpy()                    # (n_val_total, F*W)
+    out = {"hist": hist.reshape(F, W, n_iter), "bank": bank, "words": words, "folds": []}
+    pos = 0
+    for f, (_, val) in enumerate(folds):
+        sc = all_scores[pos:pos + len(val), f * W:(f + 1) * W]
+        pos += len(val)
+        pred = [words[int(np.argmax(r))] for r in sc]
+        right = sum(p == _word_of(str(n)) for p, n in zip(pred, val))
+        out["folds"].append({"scores": sc, "pred": pred, "right": right, "wrong": len(val) - right})
+    return out

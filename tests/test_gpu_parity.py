@@ -332,3 +332,30 @@ def test_fold_accuracies_identical(sra, ctx, folds_golden):
         # float32 fast path gives the same labels
         s32 = bank.score(sra.Ragged(ctx, vdata.X, offsets=vdata.offsets, dtype="float32")).cpu().numpy()
         assert [words[int(np.argmax(r))] for r in s32] == pred
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_cross_validate_batched_matches_reference(sra, ctx, folds_golden, dtype):
+    """All 30 (fold, word) models trained in one batched job: histories,
+    parameters, scores, labels and right-counts as the reference's per-fold runs."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import fold_init
+    g = folds_golden
+    words = list(g["words"])
+    folds = [(list(g[f"f{k}_train"]), list(g[f"f{k}_val"])) for k in range(1, 6)]
+    res = sra.recognizer.cross_validate(g["feats"].astype(np.float64), g["lengths"], list(g["names"]),
+                                        folds, words, n_components=3, n_iter=int(g["n_iter"]),
+                                        init_fn=fold_init, dtype=dtype, ctx=ctx)
+    sp, A, mu, cv = res["bank"].params_host()
+    tight = dtype == "float64"
+    for k in range(1, 6):
+        fr = res["folds"][k - 1]
+        assert fr["pred"] == list(g[f"f{k}_pred"])
+        assert fr["right"] == int(g[f"f{k}_right"])
+        np.testing.assert_allclose(fr["scores"], g[f"f{k}_scores"], rtol=1e-7 if tight else 2e-4)
+        for w_i, w in enumerate(words):
+            q, m = f"f{k}_{w}_", (k - 1) * len(words) + w_i
+            np.testing.assert_allclose(res["hist"][k - 1, w_i], g[q + "hist"], rtol=1e-9 if tight else 1e-5)
+            np.testing.assert_allclose(mu[m], g[q + "mu"], rtol=1e-5 if tight else 1e-3, atol=1e-7 if tight else 1e-4)
+            np.testing.assert_allclose(A[m], g[q + "A"], rtol=1e-5 if tight else 1e-3, atol=1e-9 if tight else 1e-5)
