@@ -94,20 +94,23 @@ __global__ void fused_prep_kernel(srx_models_t md, int RQ, int H, float* W, floa
         }
         W[i] = v;
     }
-    for (int i = tid; i < M * 16; i += nth) {
+    // constants: one wave per row, lanes over features
+    const int wave = tid >> 6, lane = tid & 63, n_wave = nth >> 6;
+    for (int i = wave; i < M * 16; i += n_wave) {
         const int row = i % 16, m = i / 16, s = sigma(row);
-        float v = kNegBig;
-        if (s < S) {
-            double acc = D * 1.8378770664093453;
-            for (int d = 0; d < D; ++d) {
+        double acc = 0.0;
+        if (s < S)
+            for (int d = lane; d < D; d += 64) {
                 const size_t k = ((size_t)m * S + s) * D + d;
                 const double var = fmax(md.covars[k], 2.2250738585072014e-308);
                 acc += log(var) + md.means[k] * md.means[k] / var;
             }
-            v = (float)(-0.5 * acc * 1.4426950408889634);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) {
+            cst[i] = s < S ? (float)(-0.5 * (acc + D * 1.8378770664093453) * 1.4426950408889634) : kNegBig;
+            pi[i] = (row < S) ? (float)md.startprob[m * S + row] : 0.f;   // state order
         }
-        cst[i] = v;
-        pi[i] = (row < S) ? (float)md.startprob[m * S + row] : 0.f;   // state order
     }
     for (int i = tid; i < M * 256; i += nth) {
         const int j = i & 15, ii = (i >> 4) & 15, m = i >> 8;
@@ -628,7 +631,7 @@ int srx_fused_estep(srx_context* h, const void* X, const int64_t* off, int64_t U
     hipLaunchKernelGGL(fused_batch_total_kernel, dim3((unsigned)((n_batches + 255) / 256)), dim3(256),
                        0, st, off, U, utt_order, n_batches, batch_base);
     hipLaunchKernelGGL(fused_batch_scan_kernel, dim3(1), dim3(1024), 0, st, n_batches, batch_base);
-    hipLaunchKernelGGL(fused_prep_kernel, dim3(8), dim3(256), 0, st, *md, RQ, H, base, cst, A, pi);
+    hipLaunchKernelGGL(fused_prep_kernel, dim3(24), dim3(256), 0, st, *md, RQ, H, base, cst, A, pi);
     const float* Xf = (const float*)X;
 #define SRX_CASE(rq, hh, ntx)                                                                \
     if (RQ == rq && H == hh && NTX == ntx) {                                                  \

@@ -281,6 +281,7 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 struct SplitTables {
     const unsigned* Wp;   // [NT*16 rows][RQ][2 (hi, lo)][4 lane groups][4 dwords] packed bf16 pairs
@@ -297,17 +298,22 @@ __device__ __host__ inline unsigned bf16_rne(float f) {
 
 // One thread per (row, q, part, lane group): the 8 weights facing the slots
 // [x0 x1 x2 x3 s0 s1 s2 s3] of features 16q+4g .. 16q+4g+3.
-__global__ void split_prep_kernel(srx_models_t md, int SP, int NT, int RQ, unsigned* Wp, float* cst,
-                                  float* A, float* pi) {
+// The feature axis is cut into RQ blocks of 16 (lane group g: features 16q+4g..+3)
+// and, if H, one last block of 8 (lane group g: features 16RQ+2g, +1, in slots
+// 0, 1 and 4, 5; the other slots carry zero weights).
+__global__ void split_prep_kernel(srx_models_t md, int SP, int NT, int RQ, int H, unsigned* Wp,
+                                  float* cst, float* A, float* pi) {
     const int M = md.n_models, S = md.n_states, D = md.n_features;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nth = gridDim.x * blockDim.x;
-    for (int i = tid; i < NT * 16 * RQ * 2 * 4; i += nth) {
-        const int g = i & 3, part = (i >> 2) & 1, q = (i >> 3) % RQ, row = (i >> 3) / RQ;
+    const int QT = RQ + H;
+    for (int i = tid; i < NT * 16 * QT * 2 * 4; i += nth) {
+        const int g = i & 3, part = (i >> 2) & 1, q = (i >> 3) % QT, row = (i >> 3) / QT;
         const int m = row / SP, s = row % SP;
         unsigned short v[8];
         for (int j = 0; j < 8; ++j) {
-            const int d = 16 * q + 4 * g + (j & 3);
+            int d = 16 * q + 4 * g + (j & 3);
+            if (q == RQ) d = (j & 3) < 2 ? 16 * RQ + 2 * g + (j & 3) : D;   // half block
             float wv = 0.f;
             if (m < M && s < S && d < D) {
                 const size_t k = ((size_t)m * S + s) * D + d;
@@ -343,7 +349,7 @@ __global__ void split_prep_kernel(srx_models_t md, int SP, int NT, int RQ, unsig
     for (int i = tid; i < M * S; i += nth) pi[i] = (float)md.startprob[i];
 }
 
-template <int SP, int NT, int RQ>
+template <int SP, int NT, int RQ, int H>
 __global__ __launch_bounds__(256, 2) void score_split_kernel(
     const float* __restrict__ X, const int64_t* __restrict__ off, int64_t U, int64_t n_frames,
     int M, int S, int D, SplitTables tb, double* __restrict__ out) {
@@ -375,12 +381,13 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
     const unsigned row_bytes = (unsigned)D * 4u;
 
     // ---- loop-invariant registers: packed weights, constants, transition operands
-    u32x4 wh[NT][RQ], wl[NT][RQ];
+    constexpr int QT = RQ + H;
+    u32x4 wh[NT][QT], wl[NT][QT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int q = 0; q < RQ; ++q) {
-            const unsigned* p = tb.Wp + ((((size_t)(nt * 16 + ul)) * RQ + q) * 2 * 4 + g) * 4;
+        for (int q = 0; q < QT; ++q) {
+            const unsigned* p = tb.Wp + ((((size_t)(nt * 16 + ul)) * QT + q) * 2 * 4 + g) * 4;
             wh[nt][q] = *(const u32x4*)p;
             wl[nt][q] = *(const u32x4*)(p + 16);
         }
@@ -420,14 +427,20 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
     // compiler keeps counted waits on it; steps past an utterance's end re-read
     // its last frame and change nothing.
     constexpr int PF = 4;
-    u32x4 xq[PF][RQ];
-    auto load = [&](int t, u32x4 (&dst)[RQ]) {
+    struct frame_t {
+        u32x4 v[RQ ? RQ : 1];
+        u32x2 h;
+    };
+    frame_t xq[PF];
+    const unsigned half_off = row_off - 16u * g + 64u * RQ + 8u * g;
+    auto load = [&](int t, frame_t& dst) {
         int tc = t < T ? t : T - 1;
         if (tc < 0) tc = 0;
-        const unsigned o = row_off + (unsigned)tc * row_bytes;
+        const unsigned o = (unsigned)tc * row_bytes;
 #pragma unroll
         for (int q = 0; q < RQ; ++q)
-            dst[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o + 64u * q, 0, 0);
+            dst.v[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, row_off + o + 64u * q, 0, 0);
+        if constexpr (H != 0) dst.h = __builtin_amdgcn_raw_buffer_load_b64(rsrc, half_off + o, 0, 0);
     };
 #pragma unroll
     for (int k = 0; k < PF; ++k) load(k, xq[k]);
@@ -436,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
     // product); ragged: std::false_type when every lane of the wave is known to be
     // inside its utterance at step t (no selects); lpf: float partial sums of the
     // log-probability, folded into the double by the caller.
-    auto step = [&](auto first, auto ragged, int t, const u32x4 (&xc)[RQ], float (&lpf)[NT]) {
+    auto step = [&](auto first, auto ragged, int t, const frame_t& xf, float (&lpf)[NT]) {
         f32x4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = c0[nt];
@@ -447,18 +460,18 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
             unsigned xl_[2], sl_[2];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                x[j] = __uint_as_float(xc[q][j]);
+                x[j] = __uint_as_float(xf.v[q][j]);
                 sq[j] = x[j] * x[j];
             }
             u32x4 fh, fl;
-            fh[0] = __builtin_amdgcn_perm(xc[q][1], xc[q][0], 0x07060302u);
-            fh[1] = __builtin_amdgcn_perm(xc[q][3], xc[q][2], 0x07060302u);
+            fh[0] = __builtin_amdgcn_perm(xf.v[q][1], xf.v[q][0], 0x07060302u);
+            fh[1] = __builtin_amdgcn_perm(xf.v[q][3], xf.v[q][2], 0x07060302u);
             fh[2] = __builtin_amdgcn_perm(__float_as_uint(sq[1]), __float_as_uint(sq[0]), 0x07060302u);
             fh[3] = __builtin_amdgcn_perm(__float_as_uint(sq[3]), __float_as_uint(sq[2]), 0x07060302u);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const bf16x2 a = {(__bf16)(x[2 * j] - __uint_as_float(xc[q][2 * j] & 0xffff0000u)),
-                                  (__bf16)(x[2 * j + 1] - __uint_as_float(xc[q][2 * j + 1] & 0xffff0000u))};
+                const bf16x2 a = {(__bf16)(x[2 * j] - __uint_as_float(xf.v[q][2 * j] & 0xffff0000u)),
+                                  (__bf16)(x[2 * j + 1] - __uint_as_float(xf.v[q][2 * j + 1] & 0xffff0000u))};
                 const bf16x2 b = {
                     (__bf16)(sq[2 * j] - __uint_as_float(__float_as_uint(sq[2 * j]) & 0xffff0000u)),
                     (__bf16)(sq[2 * j + 1] - __uint_as_float(__float_as_uint(sq[2 * j + 1]) & 0xffff0000u))};
@@ -479,6 +492,31 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
             for (int nt = 0; nt < NT; ++nt)
                 acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     __builtin_bit_cast(bf16x8, wl[nt][q]), bh, acc[nt], 0, 0, 0);
+        }
+        if constexpr (H != 0) {
+            // ---- last block of 8 features: two per lane, slots 0, 1 (x) and 4, 5 (x^2)
+            const float x0 = __uint_as_float(xf.h[0]), x1 = __uint_as_float(xf.h[1]);
+            const float s0 = x0 * x0, s1 = x1 * x1;
+            const bf16x2 a = {(__bf16)(x0 - __uint_as_float(xf.h[0] & 0xffff0000u)),
+                              (__bf16)(x1 - __uint_as_float(xf.h[1] & 0xffff0000u))};
+            const bf16x2 b = {(__bf16)(s0 - __uint_as_float(__float_as_uint(s0) & 0xffff0000u)),
+                              (__bf16)(s1 - __uint_as_float(__float_as_uint(s1) & 0xffff0000u))};
+            const u32x4 fh = {__builtin_amdgcn_perm(xf.h[1], xf.h[0], 0x07060302u), 0u,
+                              __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u), 0u};
+            const u32x4 fl = {__builtin_bit_cast(unsigned, a), 0u, __builtin_bit_cast(unsigned, b), 0u};
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, fh), bl = __builtin_bit_cast(bf16x8, fl);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wh[nt][RQ]), bh, acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wh[nt][RQ]), bl, acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wl[nt][RQ]), bh, acc[nt], 0, 0, 0);
         }
         // ---- recursion, all tiles stage by stage (independent chains interleave)
         const bool live = t < T;
@@ -568,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
         // vector instructions, repeated.  The matrix pipe runs beside the vector
         // pipe only where the stream alternates between them.
 #pragma unroll
-        for (int i = 0; i < PF * (RQ * 3 * NT + 4 * NT); ++i) {
+        for (int i = 0; i < PF * (QT * 3 * NT + 4 * NT); ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         }
@@ -789,12 +827,12 @@ __global__ __launch_bounds__(256) void emission_utt_split_kernel(
     }
 }
 
-template <int SP, int NT, int RQ>
+template <int SP, int NT, int RQ, int H>
 void launch_split(const float* X, const int64_t* off, int64_t U, int64_t n_frames, int M, int S,
                   int D, SplitTables tb, double* out, hipStream_t st) {
     const int64_t groups = (U + 15) / 16;
     const unsigned grid = (unsigned)((groups + 3) / 4);
-    hipLaunchKernelGGL((score_split_kernel<SP, NT, RQ>), dim3(grid), dim3(256), 0, st, X, off, U,
+    hipLaunchKernelGGL((score_split_kernel<SP, NT, RQ, H>), dim3(grid), dim3(256), 0, st, X, off, U,
                        n_frames, M, S, D, tb, out);
 }
 
@@ -826,7 +864,7 @@ int srx_mfma_emission(srx_context* h, const void* X, int64_t n_frames, const srx
     float* pi = A + (size_t)M * S * S;
     tb.Wp = base; tb.cst = cst; tb.A = A; tb.pi = pi;
     // rows of the table = columns of the output: "padded states per model" = S
-    hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, S, NT, RQ, base, cst, A, pi);
+    hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, S, NT, RQ, 0, base, cst, A, pi);
     const int NTC = NT >= 3 ? 3 : NT;
     const int chunks = (NT + NTC - 1) / NTC;
     const int64_t n_groups = (n_frames + 15) / 16;
@@ -865,7 +903,7 @@ int srx_mfma_emission_utt(srx_context* h, const void* X, const int64_t* off, int
     float* pi = A + (size_t)M * S * S;
     tb.Wp = base; tb.cst = cst; tb.A = A; tb.pi = pi;
     // one 16-row tile per model
-    hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, 16, NT, RQ, base, cst, A, pi);
+    hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, 16, NT, RQ, 0, base, cst, A, pi);
     int64_t gx = (U + 3) / 4;
     const int64_t cap = (int64_t)h->n_cu * 8;
     if (gx > cap) gx = cap;
@@ -894,8 +932,9 @@ int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
     if (R == 3) R = 4;
     if (R == 1) R = 2;
     if (!h->exact_f32 && D <= 48) {
-        const int RQ = (D + 15) / 16;
-        const size_t n_wp = (size_t)NT * 16 * RQ * 2 * 4 * 4, n_c = (size_t)NT * 16;
+        const int H = (D % 16 >= 1 && D % 16 <= 8) ? 1 : 0;
+        const int RQ = H ? D / 16 : (D + 15) / 16;
+        const size_t n_wp = (size_t)NT * 16 * (RQ + H) * 2 * 4 * 4, n_c = (size_t)NT * 16;
         unsigned* base;
         int rc = srx_ws_ensure(h, WS_PARAMS,
                                4 * (n_wp + n_c + (size_t)M * S * S + (size_t)M * S), (void**)&base);
@@ -905,21 +944,21 @@ int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
         float* A = cst + n_c;
         float* pi = A + (size_t)M * S * S;
         tb.Wp = base; tb.cst = cst; tb.A = A; tb.pi = pi;
-        hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, SP, NT, RQ, base, cst,
-                           A, pi);
+        hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, SP, NT, RQ, H, base,
+                           cst, A, pi);
         const float* Xf = (const float*)X;
-#define SRX_CASE(sp, nt, rq)                                                       \
-    if (SP == sp && NT == nt && RQ == rq) {                                        \
-        launch_split<sp, nt, rq>(Xf, off, U, n_frames, M, S, D, tb, out, st);      \
+#define SRX_CASE(sp, nt, rq, hh)                                                   \
+    if (SP == sp && NT == nt && RQ == rq && H == hh) {                             \
+        launch_split<sp, nt, rq, hh>(Xf, off, U, n_frames, M, S, D, tb, out, st);  \
         SRX_HIP(hipGetLastError());                                                \
         return SRX_OK;                                                             \
     }
-        SRX_CASE(8, 3, 3) SRX_CASE(8, 2, 3) SRX_CASE(8, 1, 3)
-        SRX_CASE(8, 3, 2) SRX_CASE(8, 2, 2) SRX_CASE(8, 1, 2)
-        SRX_CASE(8, 3, 1) SRX_CASE(8, 2, 1) SRX_CASE(8, 1, 1)
-        SRX_CASE(4, 3, 3) SRX_CASE(4, 2, 3) SRX_CASE(4, 1, 3)
-        SRX_CASE(4, 3, 2) SRX_CASE(4, 2, 2) SRX_CASE(4, 1, 2)
-        SRX_CASE(4, 3, 1) SRX_CASE(4, 2, 1) SRX_CASE(4, 1, 1)
+#define SRX_CASES(sp, nt)                                                          \
+    SRX_CASE(sp, nt, 0, 1) SRX_CASE(sp, nt, 1, 0) SRX_CASE(sp, nt, 1, 1)           \
+    SRX_CASE(sp, nt, 2, 0) SRX_CASE(sp, nt, 2, 1) SRX_CASE(sp, nt, 3, 0)
+        SRX_CASES(8, 3) SRX_CASES(8, 2) SRX_CASES(8, 1)
+        SRX_CASES(4, 3) SRX_CASES(4, 2) SRX_CASES(4, 1)
+#undef SRX_CASES
 #undef SRX_CASE
         return SRX_EUNSUPPORTED;
     }
