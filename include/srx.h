@@ -154,6 +154,31 @@ int srx_viterbi(srx_handle_t h, const void* X, int dtype, const int64_t* utt_off
                 const srx_models_t* models, int32_t* out_path, double* out_logprob,
                 void* stream);
 
+/* ---- large emission model: S states, each a mixture of n_mix diagonal
+ * Gaussians (the per-component density is hmm.py:154-163; the mixture,
+ * ln sum_m w_m N_m, is hmmlearn's GMMHMM emission -- the reference itself has
+ * single Gaussians only, which is the n_mix = 1, weight 1 case).  All arrays
+ * are device pointers, double.  out[f, s] (dtype).  The float32 path runs on the
+ * matrix cores for n_mix <= 16 and n_features <= 48. */
+typedef struct {
+    int32_t n_states, n_mix, n_features;
+    const double* weights;   /* [n_states, n_mix] */
+    const double* means;     /* [n_states, n_mix, n_features] */
+    const double* covars;    /* [n_states, n_mix, n_features] */
+} srx_gmm_t;
+int srx_gmm_emission_loglik(srx_handle_t h, const void* X, int dtype, int64_t n_frames,
+                            const srx_gmm_t* gmm, void* out, void* stream);
+
+/* ---- decoding from given log-densities over a dense transition matrix:
+ * utils.viterbi(log_startprob, log_transmat, framelogprob), utils.py:243-266,
+ * for models too large for srx_viterbi (n_states <= 1024).  loglik[f, s] (dtype),
+ * startprob[n_states] and transmat[n_states, n_states] are probabilities
+ * (double, device); zero entries are structural.  Ties take the lowest state. */
+int srx_viterbi_dense(srx_handle_t h, const void* loglik, int dtype, const int64_t* utt_offsets,
+                      int64_t n_utts, int64_t n_frames, int32_t n_states,
+                      const double* startprob, const double* transmat, int32_t* out_path,
+                      double* out_logprob, void* stream);
+
 /* ---- Baum-Welch E-step: do_estep + fit_scaling +
  * accumulate_sufficient_statistics(_scaling), hmm.py:419-433, :330-354,
  * :237-253, utils.py:132-218.  Every utterance contributes to the record of

@@ -246,6 +246,44 @@ def viterbi(p, X, lengths=None):
     return np.array(out_lp), np.concatenate(out_path)
 
 
+def gmm_log_density(X, weights, means, covars):
+    """Mixture emission ln sum_m w_sm N(x; mu_sm, var_sm) -> (T, S).  Each component is
+    the reference's diagonal density (my_hmmlearn/hmm.py:154-163); the mixture
+    itself is hmmlearn's GMMHMM emission, which the reference does not have --
+    parity unpinned beyond the n_mix = 1 case, which must equal log_density_diag."""
+    X = np.asarray(X, dtype=np.float64)
+    S, MX, D = means.shape
+    out = np.empty((X.shape[0], S))
+    with np.errstate(divide="ignore"):
+        lw = np.log(weights)
+    for s in range(S):
+        comp = log_density_diag(X, means[s], covars[s]) + lw[s][None, :]     # (T, MX)
+        mx = comp.max(axis=1, keepdims=True)
+        out[:, s] = (mx + np.log(np.exp(comp - mx).sum(axis=1, keepdims=True)))[:, 0]
+    return out
+
+
+def viterbi_dense(pi, A, log_B, lengths=None):
+    """utils.viterbi on given log-densities, vectorised over states (same
+    arithmetic and tie rule as viterbi_loops)."""
+    with np.errstate(divide="ignore"):
+        lpi, lA = np.log(pi), np.log(A)
+    lps, paths = [], []
+    for lb in split_lengths(log_B, lengths):
+        T = lb.shape[0]
+        lat = np.empty_like(lb)
+        lat[0] = lpi + lb[0]
+        for t in range(1, T):
+            lat[t] = (lat[t - 1][:, None] + lA).max(axis=0) + lb[t]
+        path = np.empty(T, dtype=np.int64)
+        path[-1] = int(np.argmax(lat[-1]))
+        lps.append(lat[-1, path[-1]])
+        for t in range(T - 2, -1, -1):
+            path[t] = int(np.argmax(lat[t] + lA[:, path[t + 1]]))
+        paths.append(path)
+    return np.array(lps), np.concatenate(paths)
+
+
 def random_params(rng, S, D):
     """Synthetic model recipe used by the benchmarks and tests: mu ~ N(0,1),
     var ~ U(0.5,1.5), pi and rows of A ~ Dirichlet(1)."""

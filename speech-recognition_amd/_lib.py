@@ -30,6 +30,11 @@ class Models(C.Structure):
                 ("means", C.c_void_p), ("covars", C.c_void_p)]
 
 
+class Gmm(C.Structure):
+    _fields_ = [("n_states", C.c_int32), ("n_mix", C.c_int32), ("n_features", C.c_int32),
+                ("weights", C.c_void_p), ("means", C.c_void_p), ("covars", C.c_void_p)]
+
+
 class Priors(C.Structure):
     _fields_ = [("startprob_prior", C.c_double), ("transmat_prior", C.c_double),
                 ("means_prior", C.c_double), ("means_weight", C.c_double),
@@ -66,6 +71,8 @@ SIGNATURES = {
     "srx_estep_stats": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, _vp, _vp, C.POINTER(Models), _vp, _vp]),
     "srx_estep_stats_generic": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, _vp, _vp, C.POINTER(Models), _vp, _vp]),
     "srx_mstep": (C.c_int, [_vp, _vp, C.POINTER(Priors), C.c_int, C.POINTER(Models), _vp]),
+    "srx_gmm_emission_loglik": (C.c_int, [_vp, _vp, C.c_int, _i64, C.POINTER(Gmm), _vp, _vp]),
+    "srx_viterbi_dense": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
 }
 
 if not os.path.exists(LIB_PATH):

@@ -182,6 +182,41 @@ int srx_viterbi(srx_handle_t h, const void* X, int dtype, const int64_t* utt_off
                                out_path, out_logprob, (hipStream_t)stream);
 }
 
+int srx_gmm_emission_loglik(srx_handle_t h, const void* X, int dtype, int64_t n_frames,
+                            const srx_gmm_t* gmm, void* out, void* stream) {
+    int rc = check_common(h, X, dtype, 0, n_frames, nullptr, "srx_gmm_emission_loglik");
+    if (rc) return rc;
+    SRX_REQUIRE(gmm != nullptr, "srx_gmm_emission_loglik: gmm is NULL");
+    SRX_REQUIRE(gmm->n_states >= 1 && gmm->n_mix >= 1 && gmm->n_features >= 1,
+                "srx_gmm_emission_loglik: Shape mismatch (n_states=%d n_mix=%d n_features=%d)",
+                gmm->n_states, gmm->n_mix, gmm->n_features);
+    SRX_REQUIRE(gmm->weights && gmm->means && gmm->covars,
+                "srx_gmm_emission_loglik: NULL parameter array");
+    if (n_frames == 0) return SRX_OK;
+    SRX_REQUIRE(out != nullptr, "srx_gmm_emission_loglik: NULL out");
+    SRX_HIP(hipSetDevice(h->device));
+    return srx_large_gmm_emission(h, X, dtype, n_frames, gmm, out, (hipStream_t)stream);
+}
+
+int srx_viterbi_dense(srx_handle_t h, const void* loglik, int dtype, const int64_t* utt_offsets,
+                      int64_t n_utts, int64_t n_frames, int32_t n_states,
+                      const double* startprob, const double* transmat, int32_t* out_path,
+                      double* out_logprob, void* stream) {
+    int rc = check_common(h, loglik, dtype, n_utts, n_frames, utt_offsets, "srx_viterbi_dense");
+    if (rc) return rc;
+    SRX_REQUIRE(n_states >= 1 && n_states <= 1024,
+                "srx_viterbi_dense: n_states %d outside [1, 1024]", n_states);
+    SRX_REQUIRE(startprob && transmat, "srx_viterbi_dense: NULL model parameter array");
+    if (n_utts == 0) return SRX_OK;
+    SRX_REQUIRE(out_logprob != nullptr && (n_frames == 0 || out_path != nullptr),
+                "srx_viterbi_dense: NULL output");
+    SRX_HIP(hipSetDevice(h->device));
+    rc = srx_large_viterbi_dense(h, loglik, dtype, utt_offsets, n_utts, n_frames, n_states,
+                                 startprob, transmat, out_path, out_logprob, (hipStream_t)stream);
+    if (rc == SRX_EUNSUPPORTED) srx_set_error("srx_viterbi_dense: shape not supported");
+    return rc;
+}
+
 static int estep_common(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
                         int64_t n_utts, int64_t n_frames, const int32_t* utt_model,
                         const int64_t* utt_order, const srx_models_t* models, double* out_stats,

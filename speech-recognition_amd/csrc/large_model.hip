@@ -1,0 +1,503 @@
+// Large emission model: S states (up to 1024), each a mixture of up to 16 diagonal
+// Gaussians, and Viterbi decoding over a dense S x S transition matrix.
+//
+// gmm_emission_kernel   out[f][s] = ln sum_m w_sm N(x_f; mu_sm, var_sm).  One state
+//     is one 16-row MFMA tile (rows = mixture components, padded with zero-weight
+//     rows), 16 frames are its columns; the contraction [W | W2] . [x ; x^2] runs
+//     as split-bf16 on v_mfma_f32_16x16x32_bf16 exactly as in score_mfma.hip.  A
+//     wave keeps FB blocks of 16 frames as B operands in registers and walks ALL
+//     states; the four waves of a workgroup share every state's weight tile
+//     through LDS (double-buffered), so the weight stream leaves L2 once per 256
+//     frames.  The log-sum-exp over a tile's 16 rows is 2 swaps deep; results are
+//     staged in LDS and leave as 64-byte runs per frame.
+// viterbi_dense_kernel  one 1024-thread workgroup decodes UB utterances step by
+//     step: thread j owns state j, delta_{t-1} of the UB utterances sits in LDS
+//     (double-buffered) and is read as broadcasts, row i of log A is one coalesced
+//     load; two utterances per packed add / max.  delta_t of every frame goes to a
+//     scratch lattice.  viterbi_backtrace_kernel then recomputes the arg max along
+//     the best path only (lowest index on ties), as utils.viterbi does
+//     (my_hmmlearn/utils.py:243-266), from the transposed log A.
+#include "srx_internal.h"
+
+#include <math.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kNegBig = -1.0e30f;
+constexpr double kLn2 = 0.6931471805599453;
+constexpr double kLog2e = 1.4426950408889634;
+
+__device__ __host__ inline unsigned bf16_rne(float f) {
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+// ------------------------------------------------------------------ GMM tables
+// Wp[state][q RQ][part 2][g 4][row 16][4 dwords]: the 8 bf16 weights facing the
+// slots [x0 x1 x2 x3 s0 s1 s2 s3] of features 16q+4g .. +3, hi and lo parts, in
+// the order the lanes of one operand read consume them (lane = 16 g + row);
+// cst[state][row] = log2e (ln w - 0.5 (D ln 2pi + sum ln var + sum mu^2 / var)).
+__global__ void gmm_prep_kernel(srx_gmm_t gm, int RQ, unsigned* __restrict__ Wp,
+                                float* __restrict__ cst) {
+    const int S = gm.n_states, MX = gm.n_mix, D = gm.n_features;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = tid; i < (int64_t)S * 16 * RQ * 2 * 4; i += nth) {
+        const int m = i & 15, g = (i >> 4) & 3, part = (i >> 6) & 1, q = (int)((i >> 7) % RQ);
+        const int s = (int)((i >> 7) / RQ);
+        unsigned short v[8];
+        for (int j = 0; j < 8; ++j) {
+            const int d = 16 * q + 4 * g + (j & 3);
+            float wv = 0.f;
+            if (m < MX && d < D) {
+                const size_t k = ((size_t)s * MX + m) * D + d;
+                const double var = fmax(gm.covars[k], 2.2250738585072014e-308);
+                wv = (float)((j >> 2) ? (-0.5 / var) * kLog2e : (gm.means[k] / var) * kLog2e);
+            }
+            const unsigned hi = bf16_rne(wv);
+            const float rem = wv - __builtin_bit_cast(float, hi << 16);
+            v[j] = (unsigned short)(part ? bf16_rne(rem) : hi);
+        }
+        for (int k = 0; k < 4; ++k) Wp[(size_t)i * 4 + k] = (unsigned)v[2 * k] | ((unsigned)v[2 * k + 1] << 16);
+    }
+    const int64_t wave = tid >> 6, n_wave = nth >> 6;
+    const int lane = (int)(tid & 63);
+    for (int64_t row = wave; row < (int64_t)S * 16; row += n_wave) {
+        const int s = (int)(row / 16), m = (int)(row % 16);
+        const bool on = m < MX;
+        double acc = 0.0;
+        if (on)
+            for (int d = lane; d < D; d += 64) {
+                const size_t k = ((size_t)s * MX + m) * D + d;
+                const double var = fmax(gm.covars[k], 2.2250738585072014e-308);
+                acc += log(var) + gm.means[k] * gm.means[k] / var;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) {
+            float c = kNegBig;
+            if (on) {
+                const double w = gm.weights[(size_t)s * MX + m];
+                if (w > 0.0) c = (float)((log(w) - 0.5 * (acc + D * 1.8378770664093453)) * kLog2e);
+            }
+            cst[row] = c;
+        }
+    }
+}
+
+__device__ __forceinline__ void split_operand(const u32x4& xc, bf16x8& bh, bf16x8& bl) {
+    float x[4], sq[4];
+    unsigned xl_[2], sl_[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        x[j] = __uint_as_float(xc[j]);
+        sq[j] = x[j] * x[j];
+    }
+    u32x4 fh;
+    fh[0] = __builtin_amdgcn_perm(xc[1], xc[0], 0x07060302u);
+    fh[1] = __builtin_amdgcn_perm(xc[3], xc[2], 0x07060302u);
+    fh[2] = __builtin_amdgcn_perm(__float_as_uint(sq[1]), __float_as_uint(sq[0]), 0x07060302u);
+    fh[3] = __builtin_amdgcn_perm(__float_as_uint(sq[3]), __float_as_uint(sq[2]), 0x07060302u);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const bf16x2 a = {(__bf16)(x[2 * j] - __uint_as_float(xc[2 * j] & 0xffff0000u)),
+                          (__bf16)(x[2 * j + 1] - __uint_as_float(xc[2 * j + 1] & 0xffff0000u))};
+        const bf16x2 b = {
+            (__bf16)(sq[2 * j] - __uint_as_float(__float_as_uint(sq[2 * j]) & 0xffff0000u)),
+            (__bf16)(sq[2 * j + 1] - __uint_as_float(__float_as_uint(sq[2 * j + 1]) & 0xffff0000u))};
+        xl_[j] = __builtin_bit_cast(unsigned, a);
+        sl_[j] = __builtin_bit_cast(unsigned, b);
+    }
+    const u32x4 fl = {xl_[0], xl_[1], sl_[0], sl_[1]};
+    bh = __builtin_bit_cast(bf16x8, fh);
+    bl = __builtin_bit_cast(bf16x8, fl);
+}
+
+// reductions over the 16 rows of a tile column: 4 registers, then lanes l^16, l^32
+__device__ __forceinline__ float col_max(f32x4 v) {
+    float s = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    unsigned u = __float_as_uint(s);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    s = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    u = __float_as_uint(s);
+    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float col_sum(f32x4 v) {
+    float s = (v[0] + v[1]) + (v[2] + v[3]);
+    unsigned u = __float_as_uint(s);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    u = __float_as_uint(s);
+    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+constexpr int kFB = 4;                 // 16-frame blocks per wave
+constexpr int kWaves = 4;              // waves per workgroup
+constexpr int kFramesPerBlock = 16 * kFB * kWaves;
+
+template <int RQ>
+__global__ __launch_bounds__(256, 2) void gmm_emission_kernel(
+    const float* __restrict__ X, int64_t n_frames, int S, int D, const unsigned* __restrict__ Wp,
+    const float* __restrict__ cst, float* __restrict__ out) {
+    constexpr int TILE = 16 * RQ * 2 * 4 * 4;          // dwords of one state's weights
+    __shared__ __attribute__((aligned(16))) unsigned s_w[2][TILE];
+    __shared__ float s_c[2][16];
+    __shared__ float s_res[kWaves][16][16 * kFB];       // [wave][state in group][frame]
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, ul = lane & 15;
+    const int64_t f_wave = (int64_t)blockIdx.x * kFramesPerBlock + (int64_t)wv * 16 * kFB;
+
+    // ---- this wave's frames as split operands, loaded once
+    bf16x8 bh[kFB][RQ], bl[kFB][RQ];
+    {
+        const int64_t f0 = f_wave < n_frames ? f_wave : 0;
+        const int64_t rest = f_wave < n_frames ? (n_frames - f0) * (int64_t)D * 4 : 0;
+        const uintptr_t a = (uintptr_t)(X + f0 * D);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        const unsigned n = (unsigned)(rest < 0xFFFFFF00ll ? rest : 0xFFFFFF00ll);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
+#pragma unroll
+        for (int fb = 0; fb < kFB; ++fb)
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const unsigned o = (unsigned)(fb * 16 + ul) * (unsigned)D * 4u + 16u * g + 64u * q;
+                const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0);   // past the end: 0
+                split_operand(x, bh[fb][q], bl[fb][q]);
+            }
+    }
+
+    // ---- weight stream: the workgroup copies state s+1 while it computes state s
+    auto stage = [&](int s, int buf) {
+        const unsigned* src = Wp + (size_t)s * TILE;
+        for (int i = threadIdx.x * 4; i < TILE; i += 256 * 4)
+            *(u32x4*)(&s_w[buf][i]) = *(const u32x4*)(src + i);
+        if (threadIdx.x < 16) s_c[buf][threadIdx.x] = cst[(size_t)s * 16 + threadIdx.x];
+    };
+    stage(0, 0);
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < S) stage(s + 1, buf ^ 1);
+        u32x4 wh[RQ], wl[RQ];
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) {
+            const unsigned* p = &s_w[buf][((q * 2) * 64 + lane) * 4];
+            wh[q] = *(const u32x4*)p;
+            wl[q] = *(const u32x4*)(p + 256);
+        }
+        f32x4 c0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c0[r] = s_c[buf][4 * g + r];
+        f32x4 acc[kFB];
+#pragma unroll
+        for (int fb = 0; fb < kFB; ++fb) acc[fb] = c0;
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, wh[q]), al = __builtin_bit_cast(bf16x8, wl[q]);
+#pragma unroll
+            for (int fb = 0; fb < kFB; ++fb)
+                acc[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[fb][q], acc[fb], 0, 0, 0);
+#pragma unroll
+            for (int fb = 0; fb < kFB; ++fb)
+                acc[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[fb][q], acc[fb], 0, 0, 0);
+#pragma unroll
+            for (int fb = 0; fb < kFB; ++fb)
+                acc[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[fb][q], acc[fb], 0, 0, 0);
+        }
+        // ---- log-sum-exp over the 16 components (rows); log2 units
+#pragma unroll
+        for (int fb = 0; fb < kFB; ++fb) {
+            const float mx = col_max(acc[fb]);
+            f32x4 e;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(acc[fb][r] - mx);
+            const float lse = mx + __builtin_amdgcn_logf(col_sum(e));
+            if (g == 0) s_res[wv][s & 15][fb * 16 + ul] = lse * (float)kLn2;
+        }
+        // ---- every 16 states: lane l writes 64 bytes of frame l
+        if ((s & 15) == 15 || s == S - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int s0 = s & ~15, ns = s - s0 + 1;
+            const int64_t f = f_wave + lane;
+            if (f < n_frames) {
+                float* o = out + f * S + s0;
+                if (ns == 16 && (S & 3) == 0) {
+#pragma unroll
+                    for (int k = 0; k < 16; k += 4)
+                        *(f32x4*)(o + k) = f32x4{s_res[wv][k][lane], s_res[wv][k + 1][lane],
+                                                 s_res[wv][k + 2][lane], s_res[wv][k + 3][lane]};
+                } else {
+                    for (int k = 0; k < ns; ++k) o[k] = s_res[wv][k][lane];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        __syncthreads();
+    }
+}
+
+// shape-generic mixture densities (any sizes, float or double): one thread per
+// (frame, state), serial over components and features
+template <typename T>
+__global__ void gmm_emission_generic_kernel(const T* __restrict__ X, int64_t n_frames, srx_gmm_t gm,
+                                            T* __restrict__ out) {
+    const int S = gm.n_states, MX = gm.n_mix, D = gm.n_features;
+    const int64_t n = n_frames * S;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t f = i / S;
+        const int s = (int)(i % S);
+        const T* x = X + f * D;
+        double best = -INFINITY, sum = 0.0;
+        for (int m = 0; m < MX; ++m) {
+            const double w = gm.weights[(size_t)s * MX + m];
+            if (!(w > 0.0)) continue;
+            double acc = D * 1.8378770664093453;
+            for (int d = 0; d < D; ++d) {
+                const size_t k = ((size_t)s * MX + m) * D + d;
+                const double var = fmax(gm.covars[k], 2.2250738585072014e-308);
+                const double df = (double)x[d] - gm.means[k];
+                acc += log(var) + df * df / var;
+            }
+            const double v = log(w) - 0.5 * acc;
+            if (v > best) {
+                sum = sum * exp(best - v) + 1.0;
+                best = v;
+            } else {
+                sum += exp(v - best);
+            }
+        }
+        out[i] = (T)(best + log(sum));
+    }
+}
+
+// ---------------------------------------------------------------- dense Viterbi
+template <typename T>
+__global__ void dense_prep_kernel(const double* __restrict__ pi, const double* __restrict__ A, int S,
+                                  T* __restrict__ logpi, T* __restrict__ logA,
+                                  T* __restrict__ logAT) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = tid; i < (int64_t)S * S; i += nth) {
+        const T v = (T)log(A[i]);                       // log 0 = -inf, as np.log does
+        logA[i] = v;
+        logAT[(i % S) * S + i / S] = v;
+    }
+    for (int64_t i = tid; i < S; i += nth) logpi[i] = (T)log(pi[i]);
+}
+
+template <typename T>
+struct Neg;
+template <>
+struct Neg<float> {
+    static __device__ float inf() { return -INFINITY; }
+};
+template <>
+struct Neg<double> {
+    static __device__ double inf() { return -INFINITY; }
+};
+
+// UB utterances per workgroup, thread j <-> state j (+ k * blockDim for S > blockDim)
+template <typename T, int UB>
+__global__ __launch_bounds__(1024) void viterbi_dense_kernel(
+    const T* __restrict__ ll, const int64_t* __restrict__ off, int64_t U, int S,
+    const T* __restrict__ logpi, const T* __restrict__ logA, T* __restrict__ delta_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vraw[];
+    T* dl = (T*)vraw;                        // [2][S][UB]: delta of the previous / this step
+    const int j = threadIdx.x;
+    const int64_t u0 = (int64_t)blockIdx.x * UB;
+    int64_t f0[UB];
+    int Tl[UB];
+    int Tmax = 0;
+#pragma unroll
+    for (int b = 0; b < UB; ++b) {
+        const int64_t u = u0 + b;
+        f0[b] = u < U ? off[u] : 0;
+        Tl[b] = u < U ? (int)(off[u + 1] - f0[b]) : 0;
+        Tmax = max(Tmax, Tl[b]);
+    }
+    const bool own = j < S;
+    // t = 0
+    if (own) {
+#pragma unroll
+        for (int b = 0; b < UB; ++b) {
+            T v = Neg<T>::inf();
+            if (Tl[b] > 0) {
+                v = logpi[j] + ll[f0[b] * S + j];
+                delta_out[f0[b] * S + j] = v;
+            }
+            dl[(size_t)j * UB + b] = v;
+        }
+    }
+    __syncthreads();
+    for (int t = 1; t < Tmax; ++t) {
+        const T* prev = dl + (size_t)((t - 1) & 1) * S * UB;
+        T* cur = dl + (size_t)(t & 1) * S * UB;
+        if (own) {
+            T best[UB];
+#pragma unroll
+            for (int b = 0; b < UB; ++b) best[b] = Neg<T>::inf();
+            const T* acol = logA + j;
+#pragma unroll 4
+            for (int i = 0; i < S; ++i) {
+                const T a = acol[(size_t)i * S];
+                const T* p = prev + (size_t)i * UB;       // same address in every lane: a broadcast
+#pragma unroll
+                for (int b = 0; b < UB; ++b) best[b] = fmax(best[b], p[b] + a);
+            }
+#pragma unroll
+            for (int b = 0; b < UB; ++b) {
+                T v = prev[(size_t)j * UB + b];           // finished utterances keep their last column
+                if (t < Tl[b]) {
+                    v = best[b] + ll[(f0[b] + t) * S + j];
+                    delta_out[(f0[b] + t) * S + j] = v;
+                }
+                cur[(size_t)j * UB + b] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// One wave per utterance: final arg max, then s_{t-1} = argmax_i delta_{t-1}(i) + log A(i, s_t)
+template <typename T>
+__global__ void viterbi_backtrace_kernel(const T* __restrict__ delta, const int64_t* __restrict__ off,
+                                         int64_t U, int S, const T* __restrict__ logAT,
+                                         int32_t* __restrict__ path, double* __restrict__ out_lp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_wave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t u = wave; u < U; u += n_wave) {
+        const int64_t f0 = off[u];
+        const int Tl = (int)(off[u + 1] - f0);
+        if (Tl <= 0) {
+            if (lane == 0) out_lp[u] = 0.0;
+            continue;
+        }
+        auto argmax = [&](const T* d, const T* arow, T* val) {
+            T best = Neg<T>::inf();
+            int arg = 0x7fffffff;
+            for (int i = lane; i < S; i += 64) {
+                const T v = arow ? d[i] + arow[i] : d[i];
+                if (v > best || arg == 0x7fffffff) {      // strict: the lowest index wins ties
+                    best = v;
+                    arg = i;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const T ob = __shfl_xor(best, o, 64);
+                const int oa = __shfl_xor(arg, o, 64);
+                if (ob > best || (ob == best && oa < arg)) {
+                    best = ob;
+                    arg = oa;
+                }
+            }
+            *val = best;
+            return arg;
+        };
+        T v;
+        int s = argmax(delta + (f0 + Tl - 1) * S, nullptr, &v);
+        if (lane == 0) {
+            out_lp[u] = (double)v;
+            path[f0 + Tl - 1] = s;
+        }
+        for (int t = Tl - 2; t >= 0; --t) {
+            s = argmax(delta + (f0 + t) * S, logAT + (size_t)s * S, &v);
+            if (lane == 0) path[f0 + t] = s;
+        }
+    }
+}
+
+template <typename T>
+int viterbi_dense_t(srx_context* h, const void* ll, const int64_t* off, int64_t U, int64_t n_frames,
+                    int S, const double* pi, const double* A, int32_t* path, double* lp,
+                    hipStream_t st) {
+    if (S > 1024) return SRX_EUNSUPPORTED;
+    T *tabs, *delta;
+    int rc = srx_ws_ensure(h, WS_PARAMS, sizeof(T) * ((size_t)2 * S * S + S), (void**)&tabs);
+    if (rc) return rc;
+    rc = srx_ws_ensure(h, WS_LATTICE, sizeof(T) * (size_t)n_frames * S, (void**)&delta);
+    if (rc) return rc;
+    T* logA = tabs;
+    T* logAT = logA + (size_t)S * S;
+    T* logpi = logAT + (size_t)S * S;
+    hipLaunchKernelGGL(dense_prep_kernel<T>, dim3(256), dim3(256), 0, st, pi, A, S, logpi, logA, logAT);
+    const int threads = ((S + 63) / 64) * 64;
+    // utterances per workgroup: as many as LDS holds twice over, at most 16
+    constexpr int UBmax = sizeof(T) == 4 ? 16 : 8;
+    const size_t lds16 = sizeof(T) * 2 * (size_t)S * UBmax;
+    if (lds16 <= 144 * 1024) {
+        auto kern = viterbi_dense_kernel<T, UBmax>;
+        SRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds16));
+        hipLaunchKernelGGL(kern, dim3((unsigned)((U + UBmax - 1) / UBmax)), dim3(threads), lds16, st,
+                           (const T*)ll, off, U, S, logpi, logA, delta);
+    } else {
+        return SRX_EUNSUPPORTED;
+    }
+    hipLaunchKernelGGL(viterbi_backtrace_kernel<T>, dim3((unsigned)((U + 3) / 4)), dim3(256), 0, st,
+                       (const T*)delta, off, U, S, logAT, path, lp);
+    SRX_HIP(hipGetLastError());
+    return SRX_OK;
+}
+
+}  // namespace
+
+int srx_large_gmm_emission(srx_context* h, const void* X, int dtype, int64_t n_frames,
+                           const srx_gmm_t* gm, void* out, hipStream_t st) {
+    const int S = gm->n_states, MX = gm->n_mix, D = gm->n_features;
+    if (dtype == SRX_F32 && !h->exact_f32 && MX <= 16 && D <= 48) {
+        const int RQ = (D + 15) / 16;
+        const size_t n_wp = (size_t)S * 16 * RQ * 2 * 4 * 4, n_c = (size_t)S * 16;
+        unsigned* base;
+        int rc = srx_ws_ensure(h, WS_PARAMS, 4 * (n_wp + n_c), (void**)&base);
+        if (rc) return rc;
+        float* cst = (float*)(base + n_wp);
+        hipLaunchKernelGGL(gmm_prep_kernel, dim3(256), dim3(256), 0, st, *gm, RQ, base, cst);
+        const unsigned grid = (unsigned)((n_frames + kFramesPerBlock - 1) / kFramesPerBlock);
+        const float* Xf = (const float*)X;
+        float* of = (float*)out;
+        if (RQ == 1)
+            hipLaunchKernelGGL(gmm_emission_kernel<1>, dim3(grid), dim3(256), 0, st, Xf, n_frames, S, D, base, cst, of);
+        else if (RQ == 2)
+            hipLaunchKernelGGL(gmm_emission_kernel<2>, dim3(grid), dim3(256), 0, st, Xf, n_frames, S, D, base, cst, of);
+        else
+            hipLaunchKernelGGL(gmm_emission_kernel<3>, dim3(grid), dim3(256), 0, st, Xf, n_frames, S, D, base, cst, of);
+        SRX_HIP(hipGetLastError());
+        return SRX_OK;
+    }
+    const int64_t n = n_frames * S;
+    unsigned grid = (unsigned)((n + 255) / 256 < (int64_t)h->n_cu * 32 ? (n + 255) / 256 : (int64_t)h->n_cu * 32);
+    if (grid < 1) grid = 1;
+    if (dtype == SRX_F64)
+        hipLaunchKernelGGL(gmm_emission_generic_kernel<double>, dim3(grid), dim3(256), 0, st,
+                           (const double*)X, n_frames, *gm, (double*)out);
+    else
+        hipLaunchKernelGGL(gmm_emission_generic_kernel<float>, dim3(grid), dim3(256), 0, st,
+                           (const float*)X, n_frames, *gm, (float*)out);
+    SRX_HIP(hipGetLastError());
+    return SRX_OK;
+}
+
+int srx_large_viterbi_dense(srx_context* h, const void* ll, int dtype, const int64_t* off, int64_t U,
+                            int64_t n_frames, int S, const double* pi, const double* A,
+                            int32_t* path, double* lp, hipStream_t st) {
+    return dtype == SRX_F64
+               ? viterbi_dense_t<double>(h, ll, off, U, n_frames, S, pi, A, path, lp, st)
+               : viterbi_dense_t<float>(h, ll, off, U, n_frames, S, pi, A, path, lp, st);
+}

@@ -114,6 +114,13 @@ int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
                    int64_t n_frames, const srx_models_t* models, double* out,
                    hipStream_t st);
 
+// Implemented in large_model.hip.
+int srx_large_gmm_emission(srx_context* h, const void* X, int dtype, int64_t n_frames,
+                           const srx_gmm_t* gm, void* out, hipStream_t st);
+int srx_large_viterbi_dense(srx_context* h, const void* ll, int dtype, const int64_t* off, int64_t U,
+                            int64_t n_frames, int S, const double* pi, const double* A,
+                            int32_t* path, double* lp, hipStream_t st);
+
 // Implemented in estep_fused.hip (float32, S <= 16, D <= 40), else SRX_EUNSUPPORTED.
 int srx_fused_estep(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
                     const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* models,

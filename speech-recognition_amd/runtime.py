@@ -250,6 +250,59 @@ class HMMBank:
         return out
 
 
+class GmmEmission:
+    """Large emission model: S states, each a mixture of n_mix diagonal Gaussians
+    (srx_gmm_t).  ``loglik(data)`` -> (n_frames, S) log-densities; with n_mix = 1
+    and weight 1 this is the reference's _log_multivariate_normal_density_diag
+    (my_hmmlearn/hmm.py:154-163)."""
+
+    def __init__(self, ctx, weights, means, covars):
+        self.ctx = ctx
+        w = np.asarray(weights, dtype=np.float64)
+        mu = np.asarray(means, dtype=np.float64)
+        cv = np.asarray(covars, dtype=np.float64)
+        if mu.ndim != 3 or cv.shape != mu.shape or w.shape != mu.shape[:2]:
+            raise ValueError("Shape mismatch")
+        if np.any(cv <= 0):
+            raise ValueError("'diag' covars must be positive")
+        if np.any(w < 0):
+            raise ValueError("mixture weights must be non-negative")
+        self.S, self.n_mix, self.D = (int(v) for v in mu.shape)
+        self.weights, self.means, self.covars = ctx.tensor(w), ctx.tensor(mu), ctx.tensor(cv)
+        self._struct = _lib.Gmm(self.S, self.n_mix, self.D, self.weights.data_ptr(),
+                                self.means.data_ptr(), self.covars.data_ptr())
+
+    def loglik(self, data, out=None):
+        if data.D != self.D:
+            raise ValueError(
+                f"Unexpected number of dimensions, got {data.D} but expected {self.D}")
+        if out is None:
+            out = torch.empty((data.n_frames, self.S), dtype=data.X.dtype, device=self.ctx.device)
+        check(lib.srx_gmm_emission_loglik(self.ctx.handle, ptr(data.X), data.code, data.n_frames,
+                                          C.byref(self._struct), ptr(out), self.ctx.stream_ptr()),
+              "srx_gmm_emission_loglik")
+        return out
+
+
+def viterbi_dense(ctx, loglik, offsets, startprob, transmat):
+    """utils.viterbi (my_hmmlearn/utils.py:243-266) for every utterance of a packed
+    (n_frames, S) log-density tensor over one dense model (S <= 1024).
+    offsets: device int64 [U+1].  Returns (logprob (U,) float64, path (n_frames,) int32)."""
+    S = int(loglik.shape[1])
+    sp = startprob if isinstance(startprob, torch.Tensor) else ctx.tensor(np.asarray(startprob, dtype=np.float64))
+    A = transmat if isinstance(transmat, torch.Tensor) else ctx.tensor(np.asarray(transmat, dtype=np.float64))
+    if tuple(sp.shape) != (S,) or tuple(A.shape) != (S, S):
+        raise ValueError("Shape mismatch")
+    code = {torch.float32: _lib.SRX_F32, torch.float64: _lib.SRX_F64}[loglik.dtype]
+    U = int(offsets.numel()) - 1
+    n_frames = int(loglik.shape[0])
+    path = torch.empty((n_frames,), dtype=torch.int32, device=ctx.device)
+    lp = torch.empty((U,), dtype=torch.float64, device=ctx.device)
+    check(lib.srx_viterbi_dense(ctx.handle, ptr(loglik), code, ptr(offsets), U, n_frames, S, ptr(sp),
+                                ptr(A), ptr(path), ptr(lp), ctx.stream_ptr()), "srx_viterbi_dense")
+    return lp, path
+
+
 class MfccPlan:
     """Front-end tables on the device for one configuration (srx_mfcc_plan_*)."""
 

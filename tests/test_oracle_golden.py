@@ -132,3 +132,23 @@ def test_c_oracle_cepstra_match_reference(mfcc_golden, i):
     cfg = _cfg(sr)
     cep = co.cepstra(sig, cfg, g["fbank1024"])
     np.testing.assert_allclose(cep, g[f"cep{i}"], rtol=1e-9, atol=1e-8)
+
+
+def test_large_model_oracle_pins(hmm_golden):
+    """The large-model oracle pieces against pinned quantities: a mixture of ONE
+    component with weight 1 is the reference's diagonal density (golden loglik),
+    and the vectorised dense Viterbi equals the loop-faithful one (golden path)."""
+    g = hmm_golden
+    for case in ("s3d26", "s8d39", "s16d39"):
+        p = case + "_"
+        mu, var = g[p + "mu"], g[p + "var"]
+        ll = ho.gmm_log_density(g[p + "X"], np.ones((mu.shape[0], 1)), mu[:, None, :], var[:, None, :])
+        np.testing.assert_allclose(ll, g[p + "loglik"], rtol=1e-12, atol=1e-12)
+        lp, path = ho.viterbi_dense(g[p + "pi"], g[p + "A"], g[p + "loglik"], g[p + "lengths"])
+        np.testing.assert_array_equal(path, g[p + "vit_path"])
+        np.testing.assert_allclose(lp, g[p + "vit_logprob"], rtol=1e-12)
+    # two equal components with weights 1/2 each: the same density again
+    p = "s8d39_"
+    mu, var = g[p + "mu"], g[p + "var"]
+    ll2 = ho.gmm_log_density(g[p + "X"], np.full((8, 2), 0.5), np.stack([mu, mu], 1), np.stack([var, var], 1))
+    np.testing.assert_allclose(ll2, g[p + "loglik"], rtol=1e-12, atol=1e-10)
