@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=96)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-large", action="store_true", help="skip the large-model (1024-state GMM) lines")
+    ap.add_argument("--large-utts", type=int, default=4096)
     ap.add_argument("--train-utts", type=int, default=131072,
                     help="utterances per GPU for the Baum-Welch extra (config: 1M total)")
     args = ap.parse_args()
@@ -233,6 +235,47 @@ def main():
                                "utterances_total": Ut * world, "frames_per_s": Ut * world * T_FRAMES / dtt,
                                "config": "6 models x 16 states x 39 dims, full M-step, stats all-reduce",
                                "logprob_model0": float(lp[0].item())}
+        if not args.no_large:
+            # large model: 1024 states x 16-component diagonal GMMs x 39 dims, 4096 x 200 frames
+            del Xt, dt_, tr
+            torch.cuda.empty_cache()
+            Sl, Ml, Ul = 1024, 16, args.large_utts
+            rl = np.random.default_rng(5)
+            em = sra.GmmEmission(ctx, rl.dirichlet(np.ones(Ml), size=Sl),
+                                 rl.standard_normal((Sl, Ml, N_FEAT)), rl.uniform(0.5, 1.5, (Sl, Ml, N_FEAT)))
+            g4 = torch.Generator(device=dev)
+            g4.manual_seed(777 + rank)
+            Xl = torch.randn((Ul * T_FRAMES, N_FEAT), device=dev, dtype=torch.float32, generator=g4)
+            offl = torch.arange(0, (Ul + 1) * T_FRAMES, T_FRAMES, device=dev, dtype=torch.int64)
+            dl = sra.Ragged(ctx, Xl, offsets=offl, dtype="float32")
+            lll = em.loglik(dl)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                em.loglik(dl, out=lll)
+            barrier()
+            dle = (time.perf_counter() - t0) / 3
+            fl = 2.0 * 2 * N_FEAT * Sl * Ml * Ul * T_FRAMES
+            extra["large_emission"] = {
+                "frames_per_s": Ul * T_FRAMES * world / dle, "ms": dle * 1e3,
+                "tflops_algorithmic": fl / dle / 1e12,
+                "mfma_frac": 3.0 * fl / dle / 1e12 / 2500.0,
+                "config": "1024 states x 16 diag components x 39 dims, log-sum-exp per state; split-bf16 "
+                          "(3 bf16 products per f32 product) against the 2.5 PFLOP/s dense bf16 peak"}
+            Al = ctx.tensor(rl.dirichlet(np.ones(Sl), size=Sl))
+            pil = ctx.tensor(rl.dirichlet(np.ones(Sl)))
+            vl, vp = sra.viterbi_dense(ctx, lll, offl, pil, Al)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                vl, vp = sra.viterbi_dense(ctx, lll, offl, pil, Al)
+            barrier()
+            dlv = (time.perf_counter() - t0) / 3
+            extra["large_viterbi"] = {
+                "frames_per_s": Ul * T_FRAMES * world / dlv, "ms": dlv * 1e3,
+                "tera_maxplus_per_s": Ul * T_FRAMES * float(Sl) * Sl / dlv / 1e12,
+                "config": "dense 1024 x 1024 log A, (max,+) S^2 per frame on the vector ALUs, "
+                          "backtrace by recomputation"}
         out["extra"] = extra
 
     if rank == 0 and world == 1 and not args.no_cpu:

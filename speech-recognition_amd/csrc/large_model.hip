@@ -143,14 +143,15 @@ __device__ __forceinline__ float col_sum(f32x4 v) {
 constexpr int kFB = 4;                 // 16-frame blocks per wave
 constexpr int kWaves = 4;              // waves per workgroup
 constexpr int kFramesPerBlock = 16 * kFB * kWaves;
+constexpr int kSPI = 2;                // states per barrier interval (divides 16)
 
 template <int RQ>
 __global__ __launch_bounds__(256, 2) void gmm_emission_kernel(
     const float* __restrict__ X, int64_t n_frames, int S, int D, const unsigned* __restrict__ Wp,
     const float* __restrict__ cst, float* __restrict__ out) {
     constexpr int TILE = 16 * RQ * 2 * 4 * 4;          // dwords of one state's weights
-    __shared__ __attribute__((aligned(16))) unsigned s_w[2][TILE];
-    __shared__ float s_c[2][16];
+    __shared__ __attribute__((aligned(16))) unsigned s_w[2][kSPI * TILE];
+    __shared__ float s_c[2][16 * kSPI];
     __shared__ float s_res[kWaves][16][16 * kFB];       // [wave][state in group][frame]
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, ul = lane & 15;
     const int64_t f_wave = (int64_t)blockIdx.x * kFramesPerBlock + (int64_t)wv * 16 * kFB;
@@ -176,63 +177,72 @@ __global__ __launch_bounds__(256, 2) void gmm_emission_kernel(
             }
     }
 
-    // ---- weight stream: the workgroup copies state s+1 while it computes state s
-    auto stage = [&](int s, int buf) {
-        const unsigned* src = Wp + (size_t)s * TILE;
-        for (int i = threadIdx.x * 4; i < TILE; i += 256 * 4)
+    // ---- weight stream: the workgroup copies the next kSPI states while it computes
+    // the current ones (one barrier per kSPI states)
+    auto stage = [&](int s0, int buf) {
+        const int ns = S - s0 < kSPI ? S - s0 : kSPI;
+        const unsigned* src = Wp + (size_t)s0 * TILE;
+        for (int i = threadIdx.x * 4; i < ns * TILE; i += 256 * 4)
             *(u32x4*)(&s_w[buf][i]) = *(const u32x4*)(src + i);
-        if (threadIdx.x < 16) s_c[buf][threadIdx.x] = cst[(size_t)s * 16 + threadIdx.x];
+        if (threadIdx.x < 16 * ns) s_c[buf][threadIdx.x] = cst[(size_t)s0 * 16 + threadIdx.x];
     };
     stage(0, 0);
     __syncthreads();
-    for (int s = 0; s < S; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < S) stage(s + 1, buf ^ 1);
-        u32x4 wh[RQ], wl[RQ];
+    for (int s0 = 0, it = 0; s0 < S; s0 += kSPI, ++it) {
+        const int buf = it & 1;
+        if (s0 + kSPI < S) stage(s0 + kSPI, buf ^ 1);
+        f32x4 acc[kSPI][kFB];
 #pragma unroll
-        for (int q = 0; q < RQ; ++q) {
-            const unsigned* p = &s_w[buf][((q * 2) * 64 + lane) * 4];
-            wh[q] = *(const u32x4*)p;
-            wl[q] = *(const u32x4*)(p + 256);
+        for (int si = 0; si < kSPI; ++si) {
+            u32x4 wh[RQ], wl[RQ];
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const unsigned* p = &s_w[buf][si * TILE + ((q * 2) * 64 + lane) * 4];
+                wh[q] = *(const u32x4*)p;
+                wl[q] = *(const u32x4*)(p + 256);
+            }
+            f32x4 c0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c0[r] = s_c[buf][si * 16 + 4 * g + r];
+#pragma unroll
+            for (int fb = 0; fb < kFB; ++fb) acc[si][fb] = c0;
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, wh[q]), al = __builtin_bit_cast(bf16x8, wl[q]);
+#pragma unroll
+                for (int fb = 0; fb < kFB; ++fb)
+                    acc[si][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[fb][q], acc[si][fb], 0, 0, 0);
+#pragma unroll
+                for (int fb = 0; fb < kFB; ++fb)
+                    acc[si][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[fb][q], acc[si][fb], 0, 0, 0);
+#pragma unroll
+                for (int fb = 0; fb < kFB; ++fb)
+                    acc[si][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[fb][q], acc[si][fb], 0, 0, 0);
+            }
         }
-        f32x4 c0;
+        // ---- log-sum-exp over the 16 components (rows); log2 units.  States past
+        // the end (S not a multiple of kSPI) compute on stale tiles and are dropped.
 #pragma unroll
-        for (int r = 0; r < 4; ++r) c0[r] = s_c[buf][4 * g + r];
-        f32x4 acc[kFB];
+        for (int si = 0; si < kSPI; ++si)
 #pragma unroll
-        for (int fb = 0; fb < kFB; ++fb) acc[fb] = c0;
+            for (int fb = 0; fb < kFB; ++fb) {
+                const float mx = col_max(acc[si][fb]);
+                f32x4 e;
 #pragma unroll
-        for (int q = 0; q < RQ; ++q) {
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, wh[q]), al = __builtin_bit_cast(bf16x8, wl[q]);
-#pragma unroll
-            for (int fb = 0; fb < kFB; ++fb)
-                acc[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[fb][q], acc[fb], 0, 0, 0);
-#pragma unroll
-            for (int fb = 0; fb < kFB; ++fb)
-                acc[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[fb][q], acc[fb], 0, 0, 0);
-#pragma unroll
-            for (int fb = 0; fb < kFB; ++fb)
-                acc[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[fb][q], acc[fb], 0, 0, 0);
-        }
-        // ---- log-sum-exp over the 16 components (rows); log2 units
-#pragma unroll
-        for (int fb = 0; fb < kFB; ++fb) {
-            const float mx = col_max(acc[fb]);
-            f32x4 e;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(acc[fb][r] - mx);
-            const float lse = mx + __builtin_amdgcn_logf(col_sum(e));
-            if (g == 0) s_res[wv][s & 15][fb * 16 + ul] = lse * (float)kLn2;
-        }
+                for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(acc[si][fb][r] - mx);
+                const float lse = mx + __builtin_amdgcn_logf(col_sum(e));
+                if (g == 0) s_res[wv][(s0 + si) & 15][fb * 16 + ul] = lse * (float)kLn2;
+            }
         // ---- every 16 states: lane l writes 64 bytes of frame l
-        if ((s & 15) == 15 || s == S - 1) {
+        const int s_last = s0 + kSPI - 1 < S - 1 ? s0 + kSPI - 1 : S - 1;
+        if ((s_last & 15) == 15 || s_last == S - 1) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int s0 = s & ~15, ns = s - s0 + 1;
+            const int sg = s_last & ~15, ns = s_last - sg + 1;
             const int64_t f = f_wave + lane;
             if (f < n_frames) {
-                float* o = out + f * S + s0;
+                float* o = out + f * S + sg;
                 if (ns == 16 && (S & 3) == 0) {
 #pragma unroll
                     for (int k = 0; k < 16; k += 4)
