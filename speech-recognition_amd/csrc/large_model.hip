@@ -1,15 +1,17 @@
 // Large emission model: S states (up to 1024), each a mixture of up to 16 diagonal
 // Gaussians, and Viterbi decoding over a dense S x S transition matrix.
 //
-// gmm_emission_kernel   out[f][s] = ln sum_m w_sm N(x_f; mu_sm, var_sm).  One state
-//     is one 16-row MFMA tile (rows = mixture components, padded with zero-weight
-//     rows), 16 frames are its columns; the contraction [W | W2] . [x ; x^2] runs
-//     as split-bf16 on v_mfma_f32_16x16x32_bf16 exactly as in score_mfma.hip.  A
-//     wave keeps FB blocks of 16 frames as B operands in registers and walks ALL
-//     states; the four waves of a workgroup share every state's weight tile
-//     through LDS (double-buffered), so the weight stream leaves L2 once per 256
-//     frames.  The log-sum-exp over a tile's 16 rows is 2 swaps deep; results are
-//     staged in LDS and leave as 64-byte runs per frame.
+// gmm_emission_kernel   out[f][s] = ln sum_m w_sm N(x_f; mu_sm, var_sm).  Four
+//     states share four 16-row MFMA tiles: row 4g+r of tile k is component 4k+r of
+//     state 4Q+g (absent components are zero-weight rows), 16 frames are the
+//     columns, so the 16 components of a state land in the 16 accumulator registers
+//     of ONE lane and the log-sum-exp needs no cross-lane step.  The contraction
+//     [W | W2] . [x ; x^2] runs as split-bf16 on v_mfma_f32_16x16x32_bf16 exactly as
+//     in score_mfma.hip.  A wave keeps FB blocks of 16 frames as B operands in
+//     registers and walks ALL states; the four waves of a workgroup share the
+//     weight tiles through LDS (double-buffered), so the weight stream leaves L2
+//     once per 256 frames.  Results are staged in LDS and leave as 64-byte runs
+//     per frame.
 // viterbi_dense_kernel  one 1024-thread workgroup decodes UB utterances step by
 //     step: thread j owns state j, delta_{t-1} of the UB utterances sits in LDS
 //     (double-buffered) and is read as broadcasts, row i of log A is one coalesced
@@ -40,23 +42,27 @@ __device__ __host__ inline unsigned bf16_rne(float f) {
 }
 
 // ------------------------------------------------------------------ GMM tables
-// Wp[state][q RQ][part 2][g 4][row 16][4 dwords]: the 8 bf16 weights facing the
+// Wp[tile][q RQ][part 2][g 4][row 16][4 dwords]: the 8 bf16 weights facing the
 // slots [x0 x1 x2 x3 s0 s1 s2 s3] of features 16q+4g .. +3, hi and lo parts, in
-// the order the lanes of one operand read consume them (lane = 16 g + row);
-// cst[state][row] = log2e (ln w - 0.5 (D ln 2pi + sum ln var + sum mu^2 / var)).
+// the order the lanes of one operand read consume them (lane = 16 g + row).
+// Row m of tile t is component 4 (t & 3) + (m & 3) of state 4 (t >> 2) + (m >> 2).
+// cst[tile][row] = log2e (ln w - 0.5 (D ln 2pi + sum ln var + sum mu^2 / var)).
 __global__ void gmm_prep_kernel(srx_gmm_t gm, int RQ, unsigned* __restrict__ Wp,
                                 float* __restrict__ cst) {
     const int S = gm.n_states, MX = gm.n_mix, D = gm.n_features;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = tid; i < (int64_t)S * 16 * RQ * 2 * 4; i += nth) {
-        const int m = i & 15, g = (i >> 4) & 3, part = (i >> 6) & 1, q = (int)((i >> 7) % RQ);
-        const int s = (int)((i >> 7) / RQ);
+    const int64_t n_tiles = 4 * (((int64_t)S + 3) / 4);
+    for (int64_t i = tid; i < n_tiles * 16 * RQ * 2 * 4; i += nth) {
+        const int row = i & 15, g = (i >> 4) & 3, part = (i >> 6) & 1, q = (int)((i >> 7) % RQ);
+        const int64_t tile = (i >> 7) / RQ;
+        const int64_t s = 4 * (tile >> 2) + (row >> 2);
+        const int m = 4 * (int)(tile & 3) + (row & 3);
         unsigned short v[8];
         for (int j = 0; j < 8; ++j) {
             const int d = 16 * q + 4 * g + (j & 3);
             float wv = 0.f;
-            if (m < MX && d < D) {
+            if (s < S && m < MX && d < D) {
                 const size_t k = ((size_t)s * MX + m) * D + d;
                 const double var = fmax(gm.covars[k], 2.2250738585072014e-308);
                 wv = (float)((j >> 2) ? (-0.5 / var) * kLog2e : (gm.means[k] / var) * kLog2e);
@@ -69,9 +75,11 @@ __global__ void gmm_prep_kernel(srx_gmm_t gm, int RQ, unsigned* __restrict__ Wp,
     }
     const int64_t wave = tid >> 6, n_wave = nth >> 6;
     const int lane = (int)(tid & 63);
-    for (int64_t row = wave; row < (int64_t)S * 16; row += n_wave) {
-        const int s = (int)(row / 16), m = (int)(row % 16);
-        const bool on = m < MX;
+    for (int64_t row = wave; row < n_tiles * 16; row += n_wave) {
+        const int64_t tile = row >> 4;
+        const int64_t s = 4 * (tile >> 2) + ((row & 15) >> 2);
+        const int m = 4 * (int)(tile & 3) + (int)(row & 3);
+        const bool on = s < S && m < MX;
         double acc = 0.0;
         if (on)
             for (int d = lane; d < D; d += 64) {
@@ -120,38 +128,17 @@ __device__ __forceinline__ void split_operand(const u32x4& xc, bf16x8& bh, bf16x
     bl = __builtin_bit_cast(bf16x8, fl);
 }
 
-// reductions over the 16 rows of a tile column: 4 registers, then lanes l^16, l^32
-__device__ __forceinline__ float col_max(f32x4 v) {
-    float s = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-    unsigned u = __float_as_uint(s);
-    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    s = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    u = __float_as_uint(s);
-    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float col_sum(f32x4 v) {
-    float s = (v[0] + v[1]) + (v[2] + v[3]);
-    unsigned u = __float_as_uint(s);
-    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    u = __float_as_uint(s);
-    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
 constexpr int kFB = 4;                 // 16-frame blocks per wave
 constexpr int kWaves = 4;              // waves per workgroup
 constexpr int kFramesPerBlock = 16 * kFB * kWaves;
-constexpr int kSPI = 2;                // states per barrier interval (divides 16)
 
 template <int RQ>
 __global__ __launch_bounds__(256, 2) void gmm_emission_kernel(
     const float* __restrict__ X, int64_t n_frames, int S, int D, const unsigned* __restrict__ Wp,
     const float* __restrict__ cst, float* __restrict__ out) {
-    constexpr int TILE = 16 * RQ * 2 * 4 * 4;          // dwords of one state's weights
-    __shared__ __attribute__((aligned(16))) unsigned s_w[2][kSPI * TILE];
-    __shared__ float s_c[2][16 * kSPI];
+    constexpr int TILE = 16 * RQ * 2 * 4 * 4;          // dwords of one tile's weights
+    __shared__ __attribute__((aligned(16))) unsigned s_w[2][4 * TILE];
+    __shared__ float s_c[2][64];
     __shared__ float s_res[kWaves][16][16 * kFB];       // [wave][state in group][frame]
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, ul = lane & 15;
     const int64_t f_wave = (int64_t)blockIdx.x * kFramesPerBlock + (int64_t)wv * 16 * kFB;
@@ -177,64 +164,82 @@ __global__ __launch_bounds__(256, 2) void gmm_emission_kernel(
             }
     }
 
-    // ---- weight stream: the workgroup copies the next kSPI states while it computes
-    // the current ones (one barrier per kSPI states)
-    auto stage = [&](int s0, int buf) {
-        const int ns = S - s0 < kSPI ? S - s0 : kSPI;
-        const unsigned* src = Wp + (size_t)s0 * TILE;
-        for (int i = threadIdx.x * 4; i < ns * TILE; i += 256 * 4)
-            *(u32x4*)(&s_w[buf][i]) = *(const u32x4*)(src + i);
-        if (threadIdx.x < 16 * ns) s_c[buf][threadIdx.x] = cst[(size_t)s0 * 16 + threadIdx.x];
-    };
-    stage(0, 0);
-    __syncthreads();
-    for (int s0 = 0, it = 0; s0 < S; s0 += kSPI, ++it) {
-        const int buf = it & 1;
-        if (s0 + kSPI < S) stage(s0 + kSPI, buf ^ 1);
-        f32x4 acc[kSPI][kFB];
+    // ---- weight stream: the workgroup copies the next four tiles (four states)
+    // while it computes the current ones; one barrier per four states
+    const int n_quads = (S + 3) / 4;
+    // (the copy is split: global loads into registers before the MFMAs, LDS writes
+    // after them, so the loads' latency hides behind the matrix work)
+    constexpr int NST = (4 * TILE + 1023) / 1024;      // 16-byte pieces per thread
+    u32x4 stg[NST];
+    float stc = 0.f;
+    auto fetch = [&](int Q) {
+        const unsigned* src = Wp + (size_t)Q * 4 * TILE;
 #pragma unroll
-        for (int si = 0; si < kSPI; ++si) {
+        for (int i = 0; i < NST; ++i) {
+            const int o = (i * 256 + threadIdx.x) * 4;
+            stg[i] = o < 4 * TILE ? *(const u32x4*)(src + o) : u32x4{0u, 0u, 0u, 0u};
+        }
+        if (threadIdx.x < 64) stc = cst[(size_t)Q * 64 + threadIdx.x];
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int o = (i * 256 + threadIdx.x) * 4;
+            if (o < 4 * TILE) *(u32x4*)(&s_w[buf][o]) = stg[i];
+        }
+        if (threadIdx.x < 64) s_c[buf][threadIdx.x] = stc;
+    };
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    for (int Q = 0; Q < n_quads; ++Q) {
+        const int buf = Q & 1;
+        if (Q + 1 < n_quads) fetch(Q + 1);
+        f32x4 acc[4][kFB];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
             u32x4 wh[RQ], wl[RQ];
 #pragma unroll
             for (int q = 0; q < RQ; ++q) {
-                const unsigned* p = &s_w[buf][si * TILE + ((q * 2) * 64 + lane) * 4];
+                const unsigned* p = &s_w[buf][k * TILE + ((q * 2) * 64 + lane) * 4];
                 wh[q] = *(const u32x4*)p;
                 wl[q] = *(const u32x4*)(p + 256);
             }
             f32x4 c0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) c0[r] = s_c[buf][si * 16 + 4 * g + r];
+            for (int r = 0; r < 4; ++r) c0[r] = s_c[buf][k * 16 + 4 * g + r];
 #pragma unroll
-            for (int fb = 0; fb < kFB; ++fb) acc[si][fb] = c0;
+            for (int fb = 0; fb < kFB; ++fb) acc[k][fb] = c0;
 #pragma unroll
             for (int q = 0; q < RQ; ++q) {
                 const bf16x8 ah = __builtin_bit_cast(bf16x8, wh[q]), al = __builtin_bit_cast(bf16x8, wl[q]);
 #pragma unroll
                 for (int fb = 0; fb < kFB; ++fb)
-                    acc[si][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[fb][q], acc[si][fb], 0, 0, 0);
+                    acc[k][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[fb][q], acc[k][fb], 0, 0, 0);
 #pragma unroll
                 for (int fb = 0; fb < kFB; ++fb)
-                    acc[si][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[fb][q], acc[si][fb], 0, 0, 0);
+                    acc[k][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[fb][q], acc[k][fb], 0, 0, 0);
 #pragma unroll
                 for (int fb = 0; fb < kFB; ++fb)
-                    acc[si][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[fb][q], acc[si][fb], 0, 0, 0);
+                    acc[k][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[fb][q], acc[k][fb], 0, 0, 0);
             }
         }
-        // ---- log-sum-exp over the 16 components (rows); log2 units.  States past
-        // the end (S not a multiple of kSPI) compute on stale tiles and are dropped.
+        // ---- log-sum-exp over this lane's 16 components of state 4Q+g; log2 units
 #pragma unroll
-        for (int si = 0; si < kSPI; ++si)
+        for (int fb = 0; fb < kFB; ++fb) {
+            float mx = fmaxf(fmaxf(acc[0][fb][0], acc[0][fb][1]), fmaxf(acc[0][fb][2], acc[0][fb][3]));
 #pragma unroll
-            for (int fb = 0; fb < kFB; ++fb) {
-                const float mx = col_max(acc[si][fb]);
-                f32x4 e;
+            for (int k = 1; k < 4; ++k)
+                mx = fmaxf(mx, fmaxf(fmaxf(acc[k][fb][0], acc[k][fb][1]), fmaxf(acc[k][fb][2], acc[k][fb][3])));
+            float sum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(acc[si][fb][r] - mx);
-                const float lse = mx + __builtin_amdgcn_logf(col_sum(e));
-                if (g == 0) s_res[wv][(s0 + si) & 15][fb * 16 + ul] = lse * (float)kLn2;
-            }
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum += __builtin_amdgcn_exp2f(acc[k][fb][r] - mx);
+            s_res[wv][(4 * Q + g) & 15][fb * 16 + ul] = (mx + __builtin_amdgcn_logf(sum)) * (float)kLn2;
+        }
         // ---- every 16 states: lane l writes 64 bytes of frame l
-        const int s_last = s0 + kSPI - 1 < S - 1 ? s0 + kSPI - 1 : S - 1;
+        const int s_last = 4 * Q + 3 < S - 1 ? 4 * Q + 3 : S - 1;
         if ((s_last & 15) == 15 || s_last == S - 1) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -256,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void gmm_emission_kernel(
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        if (Q + 1 < n_quads) commit(buf ^ 1);
         __syncthreads();
     }
 }
@@ -473,7 +479,8 @@ int srx_large_gmm_emission(srx_context* h, const void* X, int dtype, int64_t n_f
     const int S = gm->n_states, MX = gm->n_mix, D = gm->n_features;
     if (dtype == SRX_F32 && !h->exact_f32 && MX <= 16 && D <= 48) {
         const int RQ = (D + 15) / 16;
-        const size_t n_wp = (size_t)S * 16 * RQ * 2 * 4 * 4, n_c = (size_t)S * 16;
+        const size_t n_tiles = 4 * (((size_t)S + 3) / 4);
+        const size_t n_wp = n_tiles * 16 * RQ * 2 * 4 * 4, n_c = n_tiles * 16;
         unsigned* base;
         int rc = srx_ws_ensure(h, WS_PARAMS, 4 * (n_wp + n_c), (void**)&base);
         if (rc) return rc;
