@@ -391,22 +391,34 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
             wh[nt][q] = *(const u32x4*)p;
             wl[nt][q] = *(const u32x4*)(p + 16);
         }
+    // Transition operands, also split-bf16 on the K = 32 instruction: slot j < 4 of
+    // lane group g faces hi(alpha) of source row 4g+j, slot j >= 4 its lo part, so
+    //   [A_hi | A_hi] . [alpha_hi ; alpha_lo]  +  [A_lo | 0] . [alpha_hi ; *]
+    // is two MFMAs (32 cycles) where exact f32 needs four (128); the A_lo alpha_lo
+    // term (2^-18 relative) is dropped.
     f32x4 c0[NT];
-    float atop[NT][4];
+    u32x4 a_hh[NT], a_l0[NT];
     int model[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         // accumulator rows 4g..4g+3 of the tile; tile row rho = SP*h + s
+        unsigned short hi[4], lo[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             c0[nt][q] = tb.cst[nt * 16 + 4 * g + q];
-            // transition operand: out row = ul, source row = 4g+q (k-step q, lane group g)
+            // out row = ul, source row = 4g+q
             const int src = 4 * g + q, dst = ul;
             const int ms = (nt * 16 + src) / SP, md_ = (nt * 16 + dst) / SP;
             const int ss = src % SP, sd = dst % SP;
             const bool ok = ms == md_ && ms < M && ss < S && sd < S;
-            atop[nt][q] = tb.A[ok ? ((size_t)ms * S + ss) * S + sd : 0] * (ok ? 1.f : 0.f);
+            const float a = tb.A[ok ? ((size_t)ms * S + ss) * S + sd : 0] * (ok ? 1.f : 0.f);
+            const unsigned h = bf16_rne(a);
+            hi[q] = (unsigned short)h;
+            lo[q] = (unsigned short)bf16_rne(a - __uint_as_float(h << 16));
         }
+        const unsigned h01 = hi[0] | ((unsigned)hi[1] << 16), h23 = hi[2] | ((unsigned)hi[3] << 16);
+        a_hh[nt] = u32x4{h01, h23, h01, h23};
+        a_l0[nt] = u32x4{lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16), 0u, 0u};
         model[nt] = (nt * 16 + 4 * g) / SP;
     }
 
@@ -541,10 +553,20 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
                     na[nt][r] = tb.pi[ok ? m * S + s_ : 0] * (ok ? 1.f : 0.f) * b[r];
                 }
             } else {
+                const f32x4 al = alpha[nt];
+                const unsigned u0 = __float_as_uint(al[0]), u1 = __float_as_uint(al[1]);
+                const unsigned u2 = __float_as_uint(al[2]), u3 = __float_as_uint(al[3]);
+                const bf16x2 l01 = {(__bf16)(al[0] - __uint_as_float(u0 & 0xffff0000u)),
+                                    (__bf16)(al[1] - __uint_as_float(u1 & 0xffff0000u))};
+                const bf16x2 l23 = {(__bf16)(al[2] - __uint_as_float(u2 & 0xffff0000u)),
+                                    (__bf16)(al[3] - __uint_as_float(u3 & 0xffff0000u))};
+                const u32x4 bq = {__builtin_amdgcn_perm(u1, u0, 0x07060302u),
+                                  __builtin_amdgcn_perm(u3, u2, 0x07060302u),
+                                  __builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+                const bf16x8 bv = __builtin_bit_cast(bf16x8, bq);
                 f32x4 p = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    p = __builtin_amdgcn_mfma_f32_16x16x4f32(atop[nt][q], alpha[nt][q], p, 0, 0, 0);
+                p = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_hh[nt]), bv, p, 0, 0, 0);
+                p = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_l0[nt]), bv, p, 0, 0, 0);
                 na[nt] = p * b;
             }
         }
@@ -606,7 +628,7 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
         // vector instructions, repeated.  The matrix pipe runs beside the vector
         // pipe only where the stream alternates between them.
 #pragma unroll
-        for (int i = 0; i < PF * (QT * 3 * NT + 4 * NT); ++i) {
+        for (int i = 0; i < PF * (QT * 3 * NT + 2 * NT); ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         }
