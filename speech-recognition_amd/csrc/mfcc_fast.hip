@@ -131,26 +131,47 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
 #pragma unroll
     for (int q = 0; q < 8; ++q) tw16[q] = s_tw[q * (N / 16)];
 
+    // A workgroup walks a CONTIGUOUS range of chunks: the utterance under its
+    // position then advances monotonically (offsets cached in registers, no search
+    // per chunk), and the samples of chunk b+1 are requested before chunk b is
+    // transformed, so neither the offset lookups nor the sample loads stall it.
     const int64_t chunk = (int64_t)kFramesPerBlock * c.hop;
     const int64_t n_chunks = (total + chunk - 1) / chunk;
-    for (int64_t b = blockIdx.x; b < n_chunks; b += gridDim.x) {
-        const int64_t p0 = b * chunk;
-        const int64_t p1 = p0 + chunk < total ? p0 + chunk : total;
-        int64_t lo = 0, hi = U;
+    const int64_t per_block = (n_chunks + gridDim.x - 1) / gridDim.x;
+    const int64_t b_begin = (int64_t)blockIdx.x * per_block;
+    const int64_t b_end = b_begin + per_block < n_chunks ? b_begin + per_block : n_chunks;
+    if (b_begin >= b_end) return;
+    int64_t lo = 0;
+    {
+        int64_t hi = U;
+        const int64_t p0 = b_begin * chunk;
         while (hi - lo > 1) {
             const int64_t mid = (lo + hi) >> 1;
             if (so[mid] <= p0) lo = mid; else hi = mid;
         }
-        // ---- which frame does this lane group own?  (item-th frame starting in [p0, p1))
-        // The packed buffer holds < 2^32 samples here, so 32-bit division is enough.
-        bool have = false;
-        int64_t s0 = 0;
-        unsigned t = 0, row0 = 0;
+    }
+    int64_t so_lo = so[lo], so_nx = so[lo + 1];
+    const unsigned hop = (unsigned)c.hop;
+    struct Loc {
+        bool have;
+        int64_t s0;
+        unsigned t, row0;
+    };
+    // which frame does this lane group own?  (item-th frame starting in [p0, p1))
+    // The packed buffer holds < 2^32 samples here, so 32-bit division is enough.
+    auto locate = [&](int64_t bq) {
+        const int64_t p0 = bq * chunk;
+        const int64_t p1 = p0 + chunk < total ? p0 + chunk : total;
+        while (lo + 1 < U && so_nx <= p0) {      // wave-uniform
+            ++lo;
+            so_lo = so_nx;
+            so_nx = so[lo + 1];
+        }
+        Loc r{false, 0, 0u, 0u};
         int cnt = 0;
-        const unsigned hop = (unsigned)c.hop;
-        for (int64_t u = lo; u < U && so[u] < p1 && !have; ++u) {
-            const int64_t us = so[u];
-            const unsigned n = (unsigned)(so[u + 1] - us);
+        int64_t us = so_lo, ue = so_nx;
+        for (int64_t u = lo; u < U && us < p1 && !r.have; ++u) {
+            const unsigned n = (unsigned)(ue - us);
             const unsigned Tu = n < (unsigned)c.frame_len ? 0u : (n - (unsigned)c.frame_len) / hop + 1u;
             const unsigned a = p0 > us ? (unsigned)(p0 - us) : 0u;
             const unsigned ta = (a + hop - 1u) / hop;
@@ -158,30 +179,56 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
             if (tb > Tu) tb = Tu;
             const int nn = tb > ta ? (int)(tb - ta) : 0;
             if (item < cnt + nn) {
-                have = true;
-                s0 = us;
-                t = ta + (unsigned)(item - cnt);
-                row0 = (unsigned)us / hop;
+                r.have = true;
+                r.s0 = us;
+                r.t = ta + (unsigned)(item - cnt);
+                r.row0 = (unsigned)us / hop;
             }
             cnt += nn;
+            us = ue;
+            if (u + 2 <= U && us < p1 && !r.have) ue = so[u + 2];
         }
-        // ---- 1. load + window, bit-reversed register order, P-point FFT over n1
-        if (__ballot(have) == 0) continue;       // no frame starts in this chunk for this wave
-        // Loads are unconditional (a predicated load costs a branch and a full
-        // wait): indices are clamped into the frame and the zero tail of the
-        // window table removes what the FFT must not see.  A group without a
-        // frame reads the start of the buffer and stores nothing.
+        return r;
+    };
+    // Loads are unconditional (a predicated load costs a branch and a full wait):
+    // indices are clamped into the frame and the zero tail of the window table
+    // removes what the FFT must not see.  A group without a frame reads the start
+    // of the buffer and stores nothing.
+    auto fetch = [&](const Loc& l, float (&xr)[2 * P]) {
+        const float* x = audio + l.s0 + (int64_t)(l.t * hop);
+        const int lim = l.have ? c.n_used - 1
+                               : (int)(total - 1 < (int64_t)c.n_used - 1 ? total - 1 : c.n_used - 1);
+#pragma unroll
+        for (int n1 = 0; n1 < P; ++n1) {
+            const int i0 = 32 * n1 + 2 * j;
+            xr[2 * n1] = x[min(i0, lim)];
+            xr[2 * n1 + 1] = x[min(i0 + 1, lim)];
+        }
+    };
+    Loc cur = locate(b_begin);
+    float xc[2 * P];
+    fetch(cur, xc);
+    for (int64_t b = b_begin; b < b_end; ++b) {
+        Loc nxt = cur;
+        float xn[2 * P];
+        if (b + 1 < b_end) nxt = locate(b + 1);
+        fetch(nxt, xn);                           // (the last chunk's repeat is harmless)
+        const bool have = cur.have;
+        const unsigned t = cur.t, row0 = cur.row0;
+        // ---- 1. window, bit-reversed register order, P-point FFT over n1
+        const bool any = __ballot(have) != 0;     // no frame starts in this chunk for this wave?
         float re[P], im[P];
-        const float* x = audio + s0 + (int64_t)(t * hop);
-        const int lim = have ? c.n_used - 1
-                             : (int)(total - 1 < (int64_t)c.n_used - 1 ? total - 1 : c.n_used - 1);
 #pragma unroll
         for (int n1 = 0; n1 < P; ++n1) {
             const int i0 = 32 * n1 + 2 * j;
             const float2 wv = *(const float2*)(s_win + i0);
-            re[brev(n1, ilog2(P))] = x[min(i0, lim)] * wv.x;
-            im[brev(n1, ilog2(P))] = x[min(i0 + 1, lim)] * wv.y;
+            re[brev(n1, ilog2(P))] = xc[2 * n1] * wv.x;
+            im[brev(n1, ilog2(P))] = xc[2 * n1 + 1] * wv.y;
         }
+        cur = nxt;
+#pragma unroll
+        for (int i = 0; i < 2 * P; ++i) xc[i] = xn[i];
+        if (!any) continue;
         fft_regs<P>(re, im, twp);
         // ---- 2. twiddle W_H^(j k1) and 3. transpose through LDS: Y[k1][j]
 #pragma unroll
