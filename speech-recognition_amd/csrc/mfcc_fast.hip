@@ -225,10 +225,7 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
             re[brev(n1, ilog2(P))] = xc[2 * n1] * wv.x;
             im[brev(n1, ilog2(P))] = xc[2 * n1 + 1] * wv.y;
         }
-        cur = nxt;
-#pragma unroll
-        for (int i = 0; i < 2 * P; ++i) xc[i] = xn[i];
-        if (!any) continue;
+        if (any) {
         fft_regs<P>(re, im, twp);
         // ---- 2. twiddle W_H^(j k1) and 3. transpose through LDS: Y[k1][j]
 #pragma unroll
@@ -305,6 +302,12 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
             }
         }
         wave_sync();
+        }   // any
+        // hand the prefetched chunk over only now: touching xn earlier would wait
+        // for its loads before the transform instead of after it
+        cur = nxt;
+#pragma unroll
+        for (int i = 0; i < 2 * P; ++i) xc[i] = xn[i];
     }
 }
 
