@@ -58,7 +58,7 @@ def cpu_baseline(sample_utts, seed=1234):
            "vectorised_numpy_frames_per_s": sample_utts * T_FRAMES / dtv}
     from oracle import c_oracle as co
     if co.available():
-        big = 16 * sample_utts
+        big = min(16 * sample_utts, 4096)
         Xb = rng.standard_normal((big * T_FRAMES, N_FEAT))
         t2 = time.perf_counter()
         for m in range(N_MODELS):
@@ -73,7 +73,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--utts", type=int, default=N_UTTS, help="utterances per GPU (default = config)")
-    ap.add_argument("--cpu-sample", type=int, default=96)
+    ap.add_argument("--cpu-sample", type=int, default=768,
+                    help="utterances of the workload the CPU baseline is timed on (about 15 s)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the large-model (1024-state GMM) lines")

@@ -32,7 +32,10 @@ with open(os.path.join(P, f"{tag}_score_kernel_stats.csv"), "w", newline="") as 
     for r in stats:
         r["Name"] = short(r["Name"])
         w.writerow(r)
-avg_ns = [float(r["AverageNs"]) for r in stats if KERNEL in r["Name"]][0]
+krow = [r for r in stats if KERNEL in r["Name"]][0]
+avg_ns = float(krow["AverageNs"])
+import re
+kname = re.search(r"(score_split_kernel<[^>]*>)", krow["Name"]).group(1)
 
 out = {}
 for cname, sub in (("FETCH_SIZE", "prof_fetch"), ("WRITE_SIZE", "prof_write")):
@@ -55,7 +58,7 @@ res = {
     "write_size_kb_raw": out["WRITE_SIZE"],
     "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B), WRITE_SIZE exact; KB = 1024 B",
     "algorithmic_bytes_per_launch": U * T * D * 4 + U * M * 8,
-    "kernel": "score_split_kernel<8,3,3>",
+    "kernel": kname,
     "kernel_avg_ns_rocprof": avg_ns,
     "command": "rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) "
                "-- python3 bench.py --steps 10 --warmup 2 --no-extra --no-cpu",
