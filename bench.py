@@ -79,8 +79,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the large-model (1024-state GMM) lines")
     ap.add_argument("--large-utts", type=int, default=4096)
-    ap.add_argument("--train-utts", type=int, default=131072,
-                    help="utterances per GPU for the Baum-Welch extra (config: 1M total)")
+    ap.add_argument("--train-utts", type=int, default=0,
+                    help="utterances per GPU for the Baum-Welch extra (default: the config's "
+                         "1,048,576 utterances in total, split over the GPUs)")
     args = ap.parse_args()
 
     import torch
@@ -215,10 +216,12 @@ def main():
         del audio, feats
         torch.cuda.empty_cache()
         # Baum-Welch: 6 models x 16 states, utterance u trains model u mod 6
-        Ut = args.train_utts
+        Ut = args.train_utts if args.train_utts > 0 else (1 << 20) // world
         g3 = torch.Generator(device=dev)
         g3.manual_seed(4321 + rank)
-        Xt = torch.randn((Ut * T_FRAMES, N_FEAT), device=dev, dtype=torch.float32, generator=g3)
+        Xt = torch.empty((Ut * T_FRAMES, N_FEAT), device=dev, dtype=torch.float32)
+        for i0 in range(0, Ut * T_FRAMES, 1 << 24):          # 31 GB at one GPU: fill in pieces
+            Xt[i0:i0 + (1 << 24)].normal_(generator=g3)
         offt = torch.arange(0, (Ut + 1) * T_FRAMES, T_FRAMES, device=dev, dtype=torch.int64)
         dt_ = sra.Ragged(ctx, Xt, offsets=offt, dtype="float32")
         sp2, A2, mu2, cv2 = synth_models(np.random.default_rng(8), N_MODELS, 16, N_FEAT)
@@ -234,6 +237,7 @@ def main():
         dtt = (time.perf_counter() - t0) / iters
         extra["baum_welch"] = {"iter_per_s": 1.0 / dtt, "ms_per_iter": dtt * 1e3,
                                "utterances_total": Ut * world, "frames_per_s": Ut * world * T_FRAMES / dtt,
+                               "scaling": "strong (fixed total)" if args.train_utts <= 0 else "weak",
                                "config": "6 models x 16 states x 39 dims, full M-step, stats all-reduce",
                                "logprob_model0": float(lp[0].item())}
         if not args.no_large:

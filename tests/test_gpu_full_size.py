@@ -163,3 +163,38 @@ def test_viterbi_full_size_properties(sra, ctx):
         got = path[u * T:(u + 1) * T].cpu().numpy()
         assert abs(float(lp[u]) - rlp[0]) < 1e-5 * abs(rlp[0])
         assert np.mean(got == rpath) > 0.97
+
+
+def test_addressing_beyond_4gib(sra, ctx):
+    """262,144 utterances x 200 x 39 floats = 7.6 GiB of features: results for
+    utterances past the 4 GiB mark equal those of the same data processed on its own
+    (scores bit for bit, statistics to rounding of the float64 sums)."""
+    import torch
+    U, T, D, M = 1 << 18, 200, 39, 6
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    X = torch.empty((U * T, D), device="cuda", dtype=torch.float32)
+    step = 1 << 24
+    for i in range(0, U * T, step):
+        X[i:i + step].normal_(generator=g)
+    off = torch.arange(0, (U + 1) * T, T, device="cuda", dtype=torch.int64)
+    data = sra.Ragged(ctx, X, offsets=off, dtype="float32")
+    rng = np.random.default_rng(12)
+    bank8 = _bank(sra, ctx, _models(rng, M, 8, D))
+    bank16 = _bank(sra, ctx, _models(rng, M, 16, D))
+    n = 2048
+    tail = sra.Ragged(ctx, X[(U - n) * T:], offsets=off[:n + 1], dtype="float32")
+    head = sra.Ragged(ctx, X[:(U - n) * T], offsets=off[:U - n + 1], dtype="float32")
+    sc = bank8.score(data)
+    assert torch.equal(sc[U - n:], bank8.score(tail))
+    um = (np.arange(U) % M).astype(np.int32)
+    s_all = bank16.estep(data, ctx.tensor(um), None).cpu().numpy()
+    s_head = bank16.estep(head, ctx.tensor(um[:U - n]), None).cpu().numpy()
+    s_tail = bank16.estep(tail, ctx.tensor(um[U - n:]), None).cpu().numpy()
+    assert np.abs(s_all - (s_head + s_tail)).max() < 1e-9 * np.abs(s_all).max()
+    lp, path = bank8.viterbi(data, ctx.tensor(um))
+    lp_t, path_t = bank8.viterbi(tail, ctx.tensor(um[U - n:]))
+    assert torch.equal(lp[U - n:], lp_t) and torch.equal(path[(U - n) * T:], path_t)
+    ll = bank8.emission_loglik(tail)
+    ll_all_tail = bank8.emission_loglik(data)[(U - n) * T:]
+    assert torch.equal(ll, ll_all_tail)
