@@ -489,29 +489,33 @@ int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
     if (h->exact_f32 && D > 40) return SRX_EUNSUPPORTED;
     const int SP = S <= 4 ? 4 : 8;
     const int NT = (M * SP + 15) / 16;
-    if (NT > 3) return SRX_EUNSUPPORTED;
     int R = (D + 7) / 8;
     if (R == 3) R = 4;
     if (R == 1) R = 2;
-    if (!h->exact_f32 && D <= 48) {
+
+    if (!h->exact_f32 && D <= 48 && NT <= 3 * 64) {
         const int H = (D % 16 >= 1 && D % 16 <= 8) ? 1 : 0;
         const int RQ = H ? D / 16 : (D + 15) / 16;
-        const size_t n_wp = (size_t)NT * 16 * (RQ + H) * 2 * 4 * 4, n_c = (size_t)NT * 16;
+        // banks of more than 3 tiles: slices of the grid take NTC tiles each (X is read
+        // once per slice); the tables are padded to whole slices
+        const int NTC = NT <= 3 ? NT : (NT == 4 ? 2 : 3);
+        const int chunks = (NT + NTC - 1) / NTC;
+        const int NTP = chunks * NTC;
+        const size_t n_wp = (size_t)NTP * 16 * (RQ + H) * 2 * 4 * 4, n_c = (size_t)NTP * 16;
         unsigned* base;
         int rc = srx_ws_ensure(h, WS_PARAMS,
                                4 * (n_wp + n_c + (size_t)M * S * S + (size_t)M * S), (void**)&base);
         if (rc) return rc;
-        SplitTables tb;
         float* cst = (float*)(base + n_wp);
         float* A = cst + n_c;
         float* pi = A + (size_t)M * S * S;
-        tb.Wp = base; tb.cst = cst; tb.A = A; tb.pi = pi;
-        hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, SP, NT, RQ, H, base,
+        hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, SP, NTP, RQ, H, base,
                            cst, A, pi);
         const float* Xf = (const float*)X;
-        return SP == 8 ? srx_split_score_sp8(Xf, off, U, n_frames, M, S, D, NT, RQ, H, base, cst, A, pi, out, st)
-                       : srx_split_score_sp4(Xf, off, U, n_frames, M, S, D, NT, RQ, H, base, cst, A, pi, out, st);
+        return SP == 8 ? srx_split_score_sp8(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st)
+                       : srx_split_score_sp4(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st);
     }
+    if (NT > 3) return SRX_EUNSUPPORTED;
     const int KQ = 4 * R;
     const size_t n_w = (size_t)NT * 16 * KQ * 4, n_c = (size_t)NT * 16;
     float* base;

@@ -135,6 +135,8 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
     const int lane = threadIdx.x & 63, g = lane >> 4, ul = lane & 15;
     const int64_t group = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (group * 16 >= U) return;
+    // banks of more than NT tiles: blockIdx.y takes tiles [tile0, tile0 + NT)
+    const int tile0 = blockIdx.y * NT;
     const int64_t u = group * 16 + ul;
     const bool valid = u < U;
     const int64_t uc = valid ? u : U - 1;
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int q = 0; q < QT; ++q) {
-            const unsigned* p = tb.Wp + ((((size_t)(nt * 16 + ul)) * QT + q) * 2 * 4 + g) * 4;
+            const unsigned* p = tb.Wp + ((((size_t)((tile0 + nt) * 16 + ul)) * QT + q) * 2 * 4 + g) * 4;
             wh[nt][q] = *(const u32x4*)p;
             wl[nt][q] = *(const u32x4*)(p + 16);
         }
@@ -184,10 +186,10 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
         unsigned short hi[4], lo[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            c0[nt][q] = tb.cst[nt * 16 + 4 * g + q];
+            c0[nt][q] = tb.cst[(tile0 + nt) * 16 + 4 * g + q];
             // out row = ul, source row = 4g+q
             const int src = 4 * g + q, dst = ul;
-            const int ms = (nt * 16 + src) / SP, md_ = (nt * 16 + dst) / SP;
+            const int ms = ((tile0 + nt) * 16 + src) / SP, md_ = ((tile0 + nt) * 16 + dst) / SP;
             const int ss = src % SP, sd = dst % SP;
             const bool ok = ms == md_ && ms < M && ss < S && sd < S;
             const float a = tb.A[ok ? ((size_t)ms * S + ss) * S + sd : 0] * (ok ? 1.f : 0.f);
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
         const unsigned h01 = hi[0] | ((unsigned)hi[1] << 16), h23 = hi[2] | ((unsigned)hi[3] << 16);
         a_hh[nt] = u32x4{h01, h23, h01, h23};
         a_l0[nt] = u32x4{lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16), 0u, 0u};
-        model[nt] = (nt * 16 + 4 * g) / SP;
+        model[nt] = ((tile0 + nt) * 16 + 4 * g) / SP;
     }
 
     // alpha is kept UNNORMALISED: alpha_t = (A^T alpha_{t-1}) b~_t / c_{t-1}, with the
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
             if constexpr (decltype(first)::value) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = nt * 16 + 4 * g + r, m = row / SP, s_ = row % SP;
+                    const int row = (tile0 + nt) * 16 + 4 * g + r, m = row / SP, s_ = row % SP;
                     const bool ok = m < M && s_ < S;
                     na[nt][r] = tb.pi[ok ? m * S + s_ : 0] * (ok ? 1.f : 0.f) * b[r];
                 }
@@ -462,21 +464,23 @@ __device__ __forceinline__ void split_operand(const u32x4& xc, bf16x8& bh, bf16x
 
 template <int SP, int NT, int RQ, int H>
 void launch_split(const float* X, const int64_t* off, int64_t U, int64_t n_frames, int M, int S,
-                  int D, SplitTables tb, double* out, hipStream_t st) {
+                  int D, int chunks, SplitTables tb, double* out, hipStream_t st) {
     const int64_t groups = (U + 15) / 16;
     const unsigned grid = (unsigned)((groups + 3) / 4);
-    hipLaunchKernelGGL((score_split_kernel<SP, NT, RQ, H>), dim3(grid), dim3(256), 0, st, X, off, U,
-                       n_frames, M, S, D, tb, out);
+    hipLaunchKernelGGL((score_split_kernel<SP, NT, RQ, H>), dim3(grid, (unsigned)chunks), dim3(256), 0,
+                       st, X, off, U, n_frames, M, S, D, tb, out);
 }
 
 
 }  // namespace
 
 // Scoring dispatch for one padded state count (SP = 8: score_split8.hip, SP = 4:
-// score_split4.hip).  RQ full 16-feature blocks, H = 1 for an 8-feature tail.
+// score_split4.hip).  RQ full 16-feature blocks, H = 1 for an 8-feature tail; the
+// bank's tiles are taken NT at a time by `chunks` slices of the grid (the tables
+// hold chunks * NT tiles).
 int srx_split_score_sp8(const float* X, const int64_t* off, int64_t U, int64_t n_frames, int M,
-                        int S, int D, int NT, int RQ, int H, const unsigned* Wp, const float* cst,
+                        int S, int D, int NT, int chunks, int RQ, int H, const unsigned* Wp, const float* cst,
                         const float* A, const float* pi, double* out, hipStream_t st);
 int srx_split_score_sp4(const float* X, const int64_t* off, int64_t U, int64_t n_frames, int M,
-                        int S, int D, int NT, int RQ, int H, const unsigned* Wp, const float* cst,
+                        int S, int D, int NT, int chunks, int RQ, int H, const unsigned* Wp, const float* cst,
                         const float* A, const float* pi, double* out, hipStream_t st);

@@ -359,3 +359,22 @@ def test_cross_validate_batched_matches_reference(sra, ctx, folds_golden, dtype)
             np.testing.assert_allclose(res["hist"][k - 1, w_i], g[q + "hist"], rtol=1e-9 if tight else 1e-5)
             np.testing.assert_allclose(mu[m], g[q + "mu"], rtol=1e-5 if tight else 1e-3, atol=1e-7 if tight else 1e-4)
             np.testing.assert_allclose(A[m], g[q + "A"], rtol=1e-5 if tight else 1e-3, atol=1e-9 if tight else 1e-5)
+
+
+@pytest.mark.parametrize("M,S,D", [(30, 3, 26), (12, 8, 39), (7, 8, 13), (13, 5, 39), (50, 4, 20)])
+def test_scoring_banks_larger_than_three_tiles(sra, ctx, M, S, D):
+    """More state rows than one pass of the matrix-core kernel holds (3 tiles of
+    16): the bank is scored in slices of the grid, same results as the
+    shape-generic kernels and the oracle."""
+    rng = np.random.default_rng(M * 100 + S)
+    prms = [ho.random_params(rng, S, D) for _ in range(M)]
+    lengths = [1, 2, 50, 17, 33, 64, 3, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 5]
+    X = rng.standard_normal((sum(lengths), D))
+    ref = np.stack([ho.score(p, X, lengths, loops=False) for p in prms], axis=1)
+    bank = _bank(sra, ctx, prms)
+    data = sra.Ragged(ctx, X, lengths, dtype="float32")
+    got = bank.score(data).cpu().numpy()
+    gen = bank.score(data, generic=True).cpu().numpy()
+    assert got.shape == (len(lengths), M)
+    assert _rel(got, ref) < 2e-5
+    assert _rel(got, gen) < 2e-5
