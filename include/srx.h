@@ -154,6 +154,17 @@ int srx_viterbi(srx_handle_t h, const void* X, int dtype, const int64_t* utt_off
                 const srx_models_t* models, int32_t* out_path, double* out_logprob,
                 void* stream);
 
+/* ---- posteriors: score_scaling(compute_posteriors=True) +
+ * utils.backward_scaling + compute_posteriors_scaling + utils.normalize,
+ * hmm.py:308-328, utils.py:169-183, :6-30.  out_posteriors[f, s] (dtype) is the
+ * row-normalised product of the scaled forward and backward lattices under the
+ * utterance's model utt_model[u] (NULL = model 0); out_logprob[u] the forward
+ * log-probability. */
+int srx_posteriors(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
+                   int64_t n_utts, int64_t n_frames, const int32_t* utt_model,
+                   const srx_models_t* models, void* out_posteriors, double* out_logprob,
+                   void* stream);
+
 /* ---- large emission model: S states, each a mixture of n_mix diagonal
  * Gaussians (the per-component density is hmm.py:154-163; the mixture,
  * ln sum_m w_m N_m, is hmmlearn's GMMHMM emission -- the reference itself has

@@ -177,6 +177,21 @@ def score(p, X, lengths=None, loops=True):
     return np.array(out)
 
 
+def score_posteriors(p, X, lengths=None, loops=True):
+    """score_scaling with compute_posteriors=True, my_hmmlearn/hmm.py:308-328:
+    (per-utterance log-probabilities, posteriors of all samples (n, S))."""
+    fwd = forward_scaling_loops if loops else forward_scaling_vec
+    bwd = backward_scaling_loops if loops else backward_scaling_vec
+    lps, post = [], [np.empty((0, p.S))]
+    for x in split_lengths(X, lengths):
+        with np.errstate(under="ignore"):
+            B = np.exp(log_density_diag(x, p.means, p.covars))
+        lp, alpha, c = fwd(p.pi, p.A, B)
+        post.append(posteriors(alpha, bwd(p.pi, p.A, B, c)))
+        lps.append(lp)
+    return np.array(lps), np.concatenate(post)
+
+
 def estep(p, X, lengths=None, loops=True):
     """do_estep, my_hmmlearn/hmm.py:419-433 with fit_scaling :330-337 and
     accumulate_sufficient_statistics(+_scaling) :237-253, :339-354.

@@ -182,6 +182,21 @@ int srx_viterbi(srx_handle_t h, const void* X, int dtype, const int64_t* utt_off
                                out_path, out_logprob, (hipStream_t)stream);
 }
 
+int srx_posteriors(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
+                   int64_t n_utts, int64_t n_frames, const int32_t* utt_model,
+                   const srx_models_t* models, void* out_posteriors, double* out_logprob,
+                   void* stream) {
+    int rc = check_common(h, X, dtype, n_utts, n_frames, utt_offsets, "srx_posteriors");
+    if (rc) return rc;
+    if ((rc = check_models(models, "srx_posteriors"))) return rc;
+    if (n_utts == 0) return SRX_OK;
+    SRX_REQUIRE(out_logprob != nullptr && (n_frames == 0 || out_posteriors != nullptr),
+                "srx_posteriors: NULL output");
+    SRX_HIP(hipSetDevice(h->device));
+    return srx_generic_posteriors(h, X, dtype, utt_offsets, n_utts, n_frames, utt_model, models,
+                                  out_posteriors, out_logprob, (hipStream_t)stream);
+}
+
 int srx_gmm_emission_loglik(srx_handle_t h, const void* X, int dtype, int64_t n_frames,
                             const srx_gmm_t* gmm, void* out, void* stream) {
     int rc = check_common(h, X, dtype, 0, n_frames, nullptr, "srx_gmm_emission_loglik");

@@ -175,16 +175,20 @@ __global__ void score_chain_kernel(const T* __restrict__ loglik, const int64_t* 
 // Writes posteriors into `lat` (which first holds the forward lattice), and
 // accumulates start / xi / log-prob / nobs into LDS, then one partial record
 // per workgroup: partial[blockIdx][M][S*S + S + 2] = {xi, start, logprob, nobs}.
+// With partial == NULL only the posteriors and utt_lp[u] (per-utterance
+// log-probability, may itself be NULL otherwise) are produced.
 template <typename T, int SP>
 __global__ void fb_chain_kernel(const T* __restrict__ loglik, const int64_t* __restrict__ off,
                                 int64_t U, const int32_t* __restrict__ utt_model,
                                 const int64_t* __restrict__ utt_order, int M, int S,
                                 Tables<T> tb, T* __restrict__ lat, T* __restrict__ scale,
-                                double* __restrict__ partial) {
+                                double* __restrict__ partial, double* __restrict__ utt_lp) {
     extern __shared__ __attribute__((aligned(16))) double acc[];
     const int P = S * S + S + 2;
-    for (int i = threadIdx.x; i < M * P; i += blockDim.x) acc[i] = 0.0;
-    __syncthreads();
+    if (partial) {
+        for (int i = threadIdx.x; i < M * P; i += blockDim.x) acc[i] = 0.0;
+        __syncthreads();
+    }
 
     const int j = threadIdx.x % SP;
     const int64_t sub = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / SP;
@@ -194,7 +198,10 @@ __global__ void fb_chain_kernel(const T* __restrict__ loglik, const int64_t* __r
         const int m = utt_model ? utt_model[u] : 0;
         const int64_t f0 = off[u];
         const int T_len = (int)(off[u + 1] - f0);
-        if (T_len <= 0) continue;
+        if (T_len <= 0) {
+            if (utt_lp && j == 0) utt_lp[u] = 0.0;
+            continue;
+        }
         T acol[SP], arow[SP];
 #pragma unroll
         for (int i = 0; i < SP; ++i) {
@@ -261,7 +268,8 @@ __global__ void fb_chain_kernel(const T* __restrict__ loglik, const int64_t* __r
             bb = b * beta;
             gamma0 = g;
         }
-        if (j < S) {
+        if (utt_lp && j == 0) utt_lp[u] = lp;
+        if (partial && j < S) {
             double* a = acc + (size_t)m * P;
             if (T_len > 1)
                 for (int i = 0; i < S; ++i) atomicAdd(&a[j * S + i], (double)xi[i]);
@@ -272,6 +280,7 @@ __global__ void fb_chain_kernel(const T* __restrict__ loglik, const int64_t* __r
             }
         }
     }
+    if (!partial) return;
     __syncthreads();
     double* dst = partial + (size_t)blockIdx.x * M * P;
     for (int i = threadIdx.x; i < M * P; i += blockDim.x) dst[i] = acc[i];
@@ -597,6 +606,34 @@ int viterbi_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int6
     return SRX_OK;
 }
 
+// Posteriors of every frame under its utterance's model: the forward-backward
+// chain with the caller's array as the lattice, no statistics.
+template <typename T>
+int posteriors_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
+                 const int32_t* utt_model, const srx_models_t* md, void* gamma, double* lp,
+                 hipStream_t st) {
+    const int M = md->n_models, S = md->n_states, D = md->n_features;
+    Tables<T> tb;
+    int rc = prepare<T>(h, md, &tb, st);
+    if (rc) return rc;
+    T *ll, *sc;
+    rc = srx_ws_ensure(h, WS_LOGLIK, sizeof(T) * (size_t)n_frames * S, (void**)&ll);
+    if (rc) return rc;
+    rc = srx_ws_ensure(h, WS_SCALE, sizeof(T) * (size_t)n_frames, (void**)&sc);
+    if (rc) return rc;
+    // (plain float32 emission: the split-bfloat16 matrix-core emission is good to
+    // 1e-4 in the log-density, which shows in small posteriors)
+    hipLaunchKernelGGL(emission_kernel<T>, dim3(grid_for(h, U, 1)), dim3(kBlock), 0, st,
+                       (const T*)X, off, U, utt_model, 0, M, S, D, tb, ll);
+    const int sp = sub_width(S);
+    SP_DISPATCH(sp, hipLaunchKernelGGL((fb_chain_kernel<T, SP>),
+                                       dim3(grid_for(h, U, kBlock / SP)), dim3(kBlock), 0, st,
+                                       (const T*)ll, off, U, utt_model, (const int64_t*)nullptr, M,
+                                       S, tb, (T*)gamma, sc, (double*)nullptr, lp));
+    SRX_HIP(hipGetLastError());
+    return SRX_OK;
+}
+
 template <typename T>
 int estep_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
             const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* md,
@@ -629,7 +666,7 @@ int estep_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_
                        (const T*)X, off, U, utt_model, 0, M, S, D, tb, ll);
     SP_DISPATCH(sp, hipLaunchKernelGGL((fb_chain_kernel<T, SP>), dim3(g_fb), dim3(kBlock), lds, st,
                                        (const T*)ll, off, U, utt_model, utt_order, M, S, tb, lat,
-                                       sc, part));
+                                       sc, part, (double*)nullptr));
     const int slots = (S * D + kBlock - 1) / kBlock;
     SRX_REQUIRE(slots <= 16, "estep: n_states*n_features = %d exceeds %d", S * D, 16 * kBlock);
 #define OBS(SL)                                                                                   \
@@ -675,6 +712,14 @@ int srx_generic_viterbi(srx_context* h, const void* X, int dtype, const int64_t*
                         int32_t* path, double* lp, hipStream_t st) {
     return dtype == SRX_F64 ? viterbi_t<double>(h, X, off, U, n_frames, utt_model, md, path, lp, st)
                             : viterbi_t<float>(h, X, off, U, n_frames, utt_model, md, path, lp, st);
+}
+
+int srx_generic_posteriors(srx_context* h, const void* X, int dtype, const int64_t* off, int64_t U,
+                           int64_t n_frames, const int32_t* utt_model, const srx_models_t* md,
+                           void* gamma, double* lp, hipStream_t st) {
+    return dtype == SRX_F64
+               ? posteriors_t<double>(h, X, off, U, n_frames, utt_model, md, gamma, lp, st)
+               : posteriors_t<float>(h, X, off, U, n_frames, utt_model, md, gamma, lp, st);
 }
 
 int srx_generic_estep(srx_context* h, const void* X, int dtype, const int64_t* off, int64_t U,

@@ -92,6 +92,9 @@ int srx_generic_viterbi(srx_context* h, const void* X, int dtype, const int64_t*
                         int64_t U, int64_t n_frames, const int32_t* utt_model,
                         const srx_models_t* models, int32_t* path, double* logprob,
                         hipStream_t st);
+int srx_generic_posteriors(srx_context* h, const void* X, int dtype, const int64_t* off, int64_t U,
+                           int64_t n_frames, const int32_t* utt_model, const srx_models_t* md,
+                           void* gamma, double* lp, hipStream_t st);
 int srx_generic_estep(srx_context* h, const void* X, int dtype, const int64_t* off,
                       int64_t U, int64_t n_frames, const int32_t* utt_model,
                       const int64_t* utt_order, const srx_models_t* models,

@@ -178,9 +178,34 @@ class MyGaussianHMM:
         return self._bank().emission_loglik(data).cpu().numpy().astype(np.float64)
 
     def score(self, X, lengths=None, *, compute_posteriors=False):
-        """Sum over utterances of the forward log-probability, hmm.py:186-196."""
+        """Sum over utterances of the forward log-probability, hmm.py:186-196
+        (like the reference, only the log-probability is returned whatever
+        compute_posteriors says)."""
         data = self._data(X, lengths)
         return float(self._bank().score(data).sum().item())
+
+    def score_scaling(self, X, lengths=None, *, compute_posteriors):
+        """(summed log-probability, posteriors (n_samples, S)), hmm.py:308-323;
+        without compute_posteriors the second item is the reference's empty
+        (0, S) array."""
+        data = self._data(X, lengths)
+        if not compute_posteriors:
+            return (float(self._bank().score(data).sum().item()),
+                    np.empty((0, self.n_components)))
+        lp, gamma = self._bank().posteriors(data)
+        return float(lp.sum().item()), gamma.cpu().numpy().astype(np.float64)
+
+    def score_samples(self, X, lengths=None):
+        """hmmlearn's name for (log-probability, posteriors)."""
+        return self.score_scaling(X, lengths, compute_posteriors=True)
+
+    def predict_proba(self, X, lengths=None):
+        """State posteriors of every sample, (n_samples, S)."""
+        return self.score_scaling(X, lengths, compute_posteriors=True)[1]
+
+    def predict(self, X, lengths=None):
+        """Most likely state sequence (the Viterbi path, hmmlearn's default)."""
+        return self.decode(X, lengths)[1]
 
     def score_utterances(self, X, lengths=None):
         """Per-utterance forward log-probabilities (U,)."""
@@ -194,6 +219,32 @@ class MyGaussianHMM:
         data = self._data(X, lengths)
         lp, path = self._bank().viterbi(data)
         return float(lp.sum().item()), path.cpu().numpy().astype(int)
+
+    # --------------------------------------------------------------- sampling
+    def generate_sample_from_state(self, state, random_state):
+        """One draw from a state's Gaussian, hmm.py:411-417."""
+        return random_state.multivariate_normal(self.means_[state], self.covars_[state])
+
+    def sample(self, n_samples=1, random_state=None, currstate=None):
+        """(X (n_samples, D), states) drawn from the model, hmm.py:375-398;
+        random_state is a numpy RandomState (or a seed, or None for the model's).
+        The reference's own sample() stops in its covars_ getter (hmm.py:104-108
+        passes one argument too many), so this follows the code as written with
+        the diagonal covariances expanded, and no reference output pins it."""
+        if random_state is None:
+            random_state = self.random_state
+        if not hasattr(random_state, "rand"):
+            random_state = np.random.RandomState(random_state)
+        transmat_cdf = np.cumsum(self.transmat_, axis=1)
+        if currstate is None:
+            currstate = (np.cumsum(self.startprob_) > random_state.rand()).argmax()
+        states = [currstate]
+        X = [self.generate_sample_from_state(currstate, random_state)]
+        for _ in range(n_samples - 1):
+            currstate = (transmat_cdf[currstate] > random_state.rand()).argmax()
+            states.append(currstate)
+            X.append(self.generate_sample_from_state(currstate, random_state))
+        return np.atleast_2d(X), np.array(states, dtype=int)
 
     # --------------------------------------------------------------- training
     def do_estep(self, X, lengths):

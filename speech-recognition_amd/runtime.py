@@ -207,6 +207,20 @@ class HMMBank:
                               self.ctx.stream_ptr()), "srx_viterbi")
         return lp, path
 
+    def posteriors(self, data, utt_model=None):
+        """(per-utterance log-probability (U,) float64, posteriors (n_frames, S) in
+        the data's dtype): score_scaling with compute_posteriors=True,
+        my_hmmlearn/hmm.py:308-328, each utterance under its own model."""
+        self._check(data)
+        gamma = torch.empty((data.n_frames, self.S), dtype=data.X.dtype, device=self.ctx.device)
+        lp = torch.empty((data.U,), dtype=torch.float64, device=self.ctx.device)
+        um = self.ctx.tensor(np.asarray(utt_model, dtype=np.int32)) if utt_model is not None and \
+            not isinstance(utt_model, torch.Tensor) else utt_model
+        check(lib.srx_posteriors(self.ctx.handle, ptr(data.X), data.code, ptr(data.offsets), data.U,
+                                 data.n_frames, ptr(um), C.byref(self._struct), ptr(gamma), ptr(lp),
+                                 self.ctx.stream_ptr()), "srx_posteriors")
+        return lp, gamma
+
     def estep(self, data, utt_model=None, utt_order=None, out=None, generic=False):
         """Packed statistics (M, stats_size) float64 on the device."""
         self._check(data)

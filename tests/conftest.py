@@ -21,6 +21,11 @@ def hmm_golden():
 
 
 @pytest.fixture(scope="session")
+def posteriors_golden():
+    return np.load(os.path.join(GOLDEN, "posteriors_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def mfcc_golden():
     return np.load(os.path.join(GOLDEN, "mfcc_golden.npz"))
 

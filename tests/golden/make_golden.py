@@ -2,7 +2,7 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_golden.py [mfcc] [hmm] [folds]
+    python tests/golden/make_golden.py [mfcc] [hmm] [folds] [post]
 
 The reference modules are imported as they are.  ``mfcc.py`` imports three
 third-party modules that are absent here and that the code path never uses for
@@ -186,6 +186,22 @@ def make_hmm(ref_hmm, ref_utils):
     print("hmm_golden.npz:", [c[0] for c in cases])
 
 
+def make_posteriors(ref_hmm):
+    """score_scaling(compute_posteriors=True) of every hmm_golden case (its committed
+    inputs are re-used)."""
+    src = np.load(os.path.join(OUT, "hmm_golden.npz"))
+    data = {}
+    for name in src["cases"]:
+        p = str(name) + "_"
+        m = _ref_model(ref_hmm, src[p + "pi"], src[p + "A"], src[p + "mu"], src[p + "var"])
+        lp, post = m.score_scaling(src[p + "X"], src[p + "lengths"], compute_posteriors=True)
+        data[p + "logprob"], data[p + "posteriors"] = np.float64(lp), post
+    # (sample() can not be pinned: the reference's covars_ getter raises a
+    # TypeError, hmm.py:104-108, and generate_sample_from_state needs it)
+    np.savez_compressed(os.path.join(OUT, "posteriors_golden.npz"), **data)
+    print("posteriors_golden.npz:", sorted(data))
+
+
 def fold_init(X, S):
     """Deterministic initial parameters for the fold fixtures (the reference's
     own init draws from unseeded global RNG state, hmm.py:120-127)."""
@@ -259,11 +275,13 @@ def make_folds(ref_final, ref_hmm, n_iter=8):
 
 
 if __name__ == "__main__":
-    what = set(sys.argv[1:]) or {"mfcc", "hmm", "folds"}
+    what = set(sys.argv[1:]) or {"mfcc", "hmm", "folds", "post"}
     ref_mfcc, ref_final, ref_hmm, ref_utils = _import_reference()
     if "mfcc" in what:
         make_mfcc(ref_mfcc, ref_final)
     if "hmm" in what:
         make_hmm(ref_hmm, ref_utils)
+    if "post" in what:
+        make_posteriors(ref_hmm)
     if "folds" in what:
         make_folds(ref_final, ref_hmm)

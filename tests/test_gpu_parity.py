@@ -378,3 +378,67 @@ def test_scoring_banks_larger_than_three_tiles(sra, ctx, M, S, D):
     assert got.shape == (len(lengths), M)
     assert _rel(got, ref) < 2e-5
     assert _rel(got, gen) < 2e-5
+
+
+# ------------------------------------------------------------------ posteriors
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-10), ("float32", 2e-5)])
+def test_posteriors_match_reference(sra, ctx, hmm_golden, posteriors_golden, case, dtype, tol):
+    """srx_posteriors against the reference's score_scaling(compute_posteriors=True)
+    output for every utterance of the case (absolute tolerance: posteriors lie in
+    [0, 1]; float32 2e-5, float64 1e-10)."""
+    g, p = hmm_golden, case + "_"
+    bank = _bank(sra, ctx, [golden_params(g, case)])
+    data = sra.Ragged(ctx, g[p + "X"], g[p + "lengths"], dtype=dtype)
+    lp, gam = bank.posteriors(data)
+    gam = gam.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(gam, posteriors_golden[p + "posteriors"], rtol=0, atol=tol)
+    np.testing.assert_allclose(gam.sum(axis=1), 1.0, rtol=0, atol=10 * tol)
+    assert _rel(lp.cpu().numpy(), g[p + "utt_logprob"]) < (2e-5 if dtype == "float32" else 1e-11)
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-10), ("float32", 2e-5)])
+@pytest.mark.parametrize("S,D", [(3, 13), (8, 39), (16, 39), (24, 20), (5, 50)])
+def test_posteriors_ragged_multi_model(sra, ctx, S, D, dtype, tol):
+    """Every utterance under its own model, ragged lengths with 1-frame and empty
+    utterances, against the oracle."""
+    rng = np.random.default_rng(S * 100 + D)
+    M = 4
+    prms = [ho.random_params(rng, S, D) for _ in range(M)]
+    lengths = np.array([17, 1, 0, 64, 5, 33, 2, 90, 41, 8, 0, 29])
+    um = rng.integers(0, M, size=len(lengths)).astype(np.int32)
+    X = rng.standard_normal((lengths.sum(), D))
+    bank = _bank(sra, ctx, prms)
+    lp, gam = bank.posteriors(sra.Ragged(ctx, X, lengths, dtype=dtype), um)
+    lp, gam = lp.cpu().numpy(), gam.cpu().numpy().astype(np.float64)
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    for u, n in enumerate(lengths):
+        if n == 0:
+            assert lp[u] == 0.0
+            continue
+        rl, rg = ho.score_posteriors(prms[um[u]], X[off[u]:off[u + 1]], [n], loops=False)
+        assert abs(lp[u] - rl[0]) <= (2e-5 if dtype == "float32" else 1e-11) * abs(rl[0])
+        np.testing.assert_allclose(gam[off[u]:off[u + 1]], rg, rtol=0, atol=tol)
+
+
+def test_model_class_posterior_surface(sra, hmm_golden, posteriors_golden):
+    """score_scaling / score_samples / predict_proba / predict / sample of the
+    model class."""
+    g, p = hmm_golden, "s3d26_"
+    m = sra.MyGaussianHMM(n_components=3, verbose=False)
+    prm = golden_params(g, "s3d26")
+    m.startprob_, m.transmat_, m.means_, m._covars_ = prm.pi, prm.A, prm.means, prm.covars
+    X, L = g[p + "X"], g[p + "lengths"]
+    lp, post = m.score_scaling(X, L, compute_posteriors=True)
+    np.testing.assert_allclose(lp, posteriors_golden[p + "logprob"], rtol=1e-11)
+    np.testing.assert_allclose(post, posteriors_golden[p + "posteriors"], rtol=0, atol=1e-10)
+    lp0, none = m.score_scaling(X, L, compute_posteriors=False)
+    assert none.shape == (0, 3) and abs(lp0 - lp) < 1e-9 * abs(lp)
+    np.testing.assert_array_equal(m.predict_proba(X, L), post)
+    assert m.score_samples(X, L)[0] == lp
+    np.testing.assert_array_equal(m.predict(X, L), g[p + "vit_path"])
+    Xs, states = m.sample(25, random_state=np.random.RandomState(3))
+    assert Xs.shape == (25, 26) and states.shape == (25,) and states.max() < 3
+    Xs2, states2 = m.sample(25, random_state=np.random.RandomState(3))
+    np.testing.assert_array_equal(Xs, Xs2)
+    np.testing.assert_array_equal(states, states2)

@@ -83,6 +83,18 @@ def test_lattices_match_reference(hmm_golden, case):
 
 
 @pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("loops", [True, False])
+def test_posteriors_match_reference(hmm_golden, posteriors_golden, case, loops):
+    g, p = hmm_golden, case + "_"
+    prm = golden_params(g, case)
+    lps, post = ho.score_posteriors(prm, g[p + "X"], g[p + "lengths"], loops=loops)
+    np.testing.assert_allclose(lps.sum(), posteriors_golden[p + "logprob"], rtol=1e-12)
+    np.testing.assert_allclose(post, posteriors_golden[p + "posteriors"], rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(post[: int(g[p + "lengths"][0])], g[p + "gamma0"], rtol=1e-9,
+                               atol=1e-300)
+
+
+@pytest.mark.parametrize("case", CASES)
 def test_viterbi_matches_reference(hmm_golden, case):
     g, p = hmm_golden, case + "_"
     prm = golden_params(g, case)
