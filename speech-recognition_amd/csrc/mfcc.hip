@@ -17,6 +17,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -390,6 +391,81 @@ int srx_mfcc_plan_create(srx_handle_t h, const srx_mfcc_cfg_t* cfg, srx_mfcc_pla
         for (int q = q0; q < q1; ++q)
             if (bins[q] != starts[m] + (q - q0)) p->fast_ok = 0;
     }
+    // ---- block tables of the fast kernel's mel and DCT stages.  A 4x4x1 matrix
+    // instruction is 16 independent 4x4 outer products, one per group of 4 lanes:
+    // a block = 4 consecutive filters x a range of bins (first bin a multiple of 4,
+    // mm_nq quads of bins).  One block per group of 4 filters to begin with, then the
+    // longest ranges are halved until all 16 blocks are in use.
+    p->mm_ok = 0;
+    if (p->fast_ok && cfg->n_mel <= 64 && cfg->n_ceps <= 16 && (N == 512 || N == 1024)) {
+        struct Blk { int g, lo, hi; };
+        const int G = (cfg->n_mel + 3) / 4, PW = H + 4;
+        std::vector<Blk> blk;
+        for (int g = 0; g < G; ++g) {
+            int lo = 1 << 30, hi = 0;
+            for (int m = 4 * g; m < 4 * g + 4 && m < cfg->n_mel; ++m)
+                if (ptr[m + 1] > ptr[m]) {
+                    lo = std::min(lo, (int)starts[m]);
+                    hi = std::max(hi, (int)starts[m] + (ptr[m + 1] - ptr[m]));
+                }
+            if (hi == 0) lo = 0;
+            blk.push_back({g, lo & ~3, hi});
+        }
+        auto quads = [](const Blk& b) { return (b.hi - b.lo + 3) / 4; };
+        while (blk.size() < 16) {
+            size_t best = 0;
+            for (size_t i = 1; i < blk.size(); ++i)
+                if (quads(blk[i]) > quads(blk[best])) best = i;
+            const int q = quads(blk[best]);
+            if (q <= 1) break;
+            const int mid = blk[best].lo + 4 * (q / 2);
+            Blk tail{blk[best].g, mid, blk[best].hi};
+            blk[best].hi = mid;
+            blk.insert(blk.begin() + best + 1, tail);
+        }
+        int nq = 1;
+        for (const Blk& b : blk) nq = std::max(nq, quads(b));
+        const int kk = (((cfg->n_mel + 3) / 4) + 3) & ~3;      // filters per DCT split, a multiple of 4
+        std::vector<float> w4((size_t)nq * 64 * 4, 0.f), dctA((size_t)64 * kk, 0.f);
+        std::vector<int32_t> meta(48, 0);
+        for (size_t b = 0; b < blk.size(); ++b) {
+            int k0 = blk[b].lo;
+            if (k0 + 4 * nq > PW) k0 = PW - 4 * nq;
+            meta[b] = k0;
+            if (b == 0 || blk[b - 1].g != blk[b].g) meta[16 + blk[b].g] = (int32_t)b;
+            meta[32 + blk[b].g] += 1;
+            for (int i = 0; i < 4; ++i) {
+                const int m = 4 * blk[b].g + i;
+                if (m >= cfg->n_mel) continue;
+                for (int q = ptr[m]; q < ptr[m + 1]; ++q) {
+                    const int bin = bins[q];
+                    if (bin < blk[b].lo || bin >= blk[b].hi) continue;
+                    const int rel = bin - k0;
+                    w4[((size_t)(rel / 4) * 64 + 4 * b + i) * 4 + rel % 4] = (float)w[q];
+                }
+            }
+        }
+        for (int l = 0; l < 64; ++l) {
+            const int ks = l >> 4, cg = (l >> 2) & 3, i = l & 3, k = 4 * cg + i;
+            for (int s = 0; s < kk; ++s) {
+                const int m = ks * kk + s;
+                if (k < cfg->n_ceps && m < cfg->n_mel) {
+                    double v = sqrt(2.0 / cfg->n_mel) * cos(M_PI * k * (2 * m + 1) / (2.0 * cfg->n_mel));
+                    if (k == 0) v *= 1.0 / sqrt(2.0);
+                    dctA[(size_t)l * kk + s] = (float)v;
+                }
+            }
+        }
+        if (4 * nq <= PW) {
+            SRX_HIP(hipMalloc(&p->mm_w, sizeof(float) * w4.size()));
+            SRX_HIP(hipMemcpy(p->mm_w, w4.data(), sizeof(float) * w4.size(), hipMemcpyHostToDevice));
+            SRX_HIP(hipMalloc(&p->mm_dct, sizeof(float) * dctA.size()));
+            SRX_HIP(hipMemcpy(p->mm_dct, dctA.data(), sizeof(float) * dctA.size(), hipMemcpyHostToDevice));
+            SRX_HIP(hipMalloc((void**)&p->mm_meta, sizeof(int32_t) * meta.size()));
+            SRX_HIP(hipMemcpy(p->mm_meta, meta.data(), sizeof(int32_t) * meta.size(), hipMemcpyHostToDevice));
+            p->mm_nq = nq; p->mm_kk = kk; p->mm_groups = G; p->mm_ok = 1;
+        }
+    }
     std::vector<float> twf(2 * (size_t)N);
     for (int k = 0; k < N; ++k) {
         twf[2 * k] = (float)cos(2.0 * M_PI * k / N);
@@ -435,6 +511,9 @@ int srx_mfcc_plan_destroy(srx_mfcc_plan_t p) {
     (void)hipFree(p->mel_ptr);
     (void)hipFree(p->tw_full);
     (void)hipFree(p->mel_start);
+    (void)hipFree(p->mm_w);
+    (void)hipFree(p->mm_dct);
+    (void)hipFree(p->mm_meta);
     delete p;
     return SRX_OK;
 }

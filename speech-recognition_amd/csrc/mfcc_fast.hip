@@ -10,8 +10,15 @@
 //   3. the group transposes through LDS ([k1][j], rows padded to 17) and every
 //      lane does 16-point FFTs over j for its k1 (one for P=16, two for P=32);
 //   4. Z goes back to LDS in natural order; the real-input spectrum is unpacked
-//      from Z[k], Z[H-k], squared and scaled; mel triangles (each a contiguous
-//      run of bins), log10, DCT rows -- tables for all of it live in LDS.
+//      from Z[k], Z[H-k], squared and scaled into the power spectrum pw[H+1];
+//   5. mel energies and DCT rows on the matrix cores, as 4x4x1 instructions: each
+//      is 16 independent 4x4 outer products, one per group of 4 lanes (lane 4b+i
+//      gives row i of A and column i of B; D[i][j] lands in register i of lane
+//      4b+j).  Rows are 4 filters (then 4 cepstra), columns the wave's 4 frames; a
+//      block walks its own range of bins, a quad per step (tables built with the
+//      plan: weights per (quad, lane), first bin per block).  Blocks that share
+//      filters add up through LDS; log10; the DCT's 16 blocks are 4 groups of
+//      cepstra x 4 slices of the filters, added across lanes at the end.
 // A wave carries 4 frames at once, a workgroup 16; work items are cut from the
 // packed sample axis exactly as in the generic kernel (mfcc.hip).
 #include "srx_internal.h"
@@ -28,11 +35,31 @@ struct FastDev {
     float log_mult;
     const float* window;      // [frame_len]
     const float2* tw;         // [N] exp(-2 pi i k / N)
-    const int32_t* mel_ptr;   // [n_mel+1]
-    const int32_t* mel_start; // [n_mel] first bin of each filter's run
-    const float* mel_w;       // [nnz]
-    const float* dct;         // [n_ceps][n_mel]
+    int nq, kk, groups;       // quads of bins per block, filters per DCT slice, groups of 4 filters
+    const float* mm_w;        // [nq][64][4]
+    const float* mm_dct;      // [64][kk]
+    const int32_t* mm_meta;   // [16] first bin, [16] first block, [16] blocks of a group
 };
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// a * b where a zero factor gives 0 whatever the other one is (inf, NaN)
+__device__ __forceinline__ float mul_zero_wins(float a, float b) {
+    float r;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ float sum_rows(float v) {
+    // v[l] + v[l^16] + v[l^32] + v[l^48]
+    unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    u = __float_as_uint(v);
+    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -95,23 +122,20 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
     float2* s_tw = (float2*)smem_raw;                       // [N]
     float* s_win = (float*)(s_tw + N);                      // [N], zero past the samples the FFT uses
     const int lpad = N;
-    float* s_melw = s_win + lpad;                           // [nnz rounded to 4]
-    const int wpad = (c.nnz + 3) & ~3;
-    int* s_melptr = (int*)(s_melw + wpad);                  // [n_mel+1]
-    int* s_melstart = s_melptr + ((c.n_mel + 1 + 3) & ~3);  // [n_mel]
-    const int mpad = (c.n_mel + 3) & ~3;
-    float* s_dct = (float*)(s_melstart + mpad);             // [n_ceps][n_mel+1]
-    const int drow = c.n_mel + 1;
-    float2* s_tw2 = (float2*)(s_dct + ((c.n_ceps * drow + 3) & ~3));   // [P][16]: W_H^(j k1)
+    float* s_w4 = s_win + lpad;                             // [nq][64][4]
+    float* s_dctA = s_w4 + (size_t)c.nq * 256;              // [64][kk]
+    int* s_meta = (int*)(s_dctA + 64 * c.kk);               // [48]
+    float2* s_tw2 = (float2*)(s_meta + 48);                 // [P][16]: W_H^(j k1)
     float* s_frames = (float*)(s_tw2 + P * 16);
-    const int per_frame = 2 * YS + (H + 4) + ((c.n_mel + 3) & ~3);   // floats
+    const int per_frame = 2 * YS + (H + 4) + 4 * c.kk;      // floats
     for (int i = threadIdx.x; i < N; i += blockDim.x) s_tw[i] = c.tw[i];
     for (int i = threadIdx.x; i < N; i += blockDim.x) s_win[i] = i < c.n_used ? c.window[i] : 0.f;
-    for (int i = threadIdx.x; i < c.nnz; i += blockDim.x) s_melw[i] = c.mel_w[i];
-    for (int i = threadIdx.x; i <= c.n_mel; i += blockDim.x) s_melptr[i] = c.mel_ptr[i];
-    for (int i = threadIdx.x; i < c.n_mel; i += blockDim.x) s_melstart[i] = c.mel_start[i];
-    for (int i = threadIdx.x; i < c.n_ceps * c.n_mel; i += blockDim.x)
-        s_dct[(i / c.n_mel) * drow + i % c.n_mel] = c.dct[i];
+    for (int i = threadIdx.x; i < c.nq * 256; i += blockDim.x) s_w4[i] = c.mm_w[i];
+    for (int i = threadIdx.x; i < 64 * c.kk; i += blockDim.x) s_dctA[i] = c.mm_dct[i];
+    for (int i = threadIdx.x; i < 48; i += blockDim.x) s_meta[i] = c.mm_meta[i];
+    // the padding behind the power spectra and the log-mel rows meets zero weights:
+    // it must hold finite numbers
+    for (int i = threadIdx.x; i < kFramesPerBlock * per_frame; i += blockDim.x) s_frames[i] = 0.f;
     for (int i = threadIdx.x; i < P * 16; i += blockDim.x)
         s_tw2[i] = c.tw[2 * (((i & 15) * (i >> 4)) & (H - 1))];
     __syncthreads();
@@ -122,7 +146,15 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
     float* fr = s_frames + (size_t)item * per_frame;
     float2* Y = (float2*)fr;                          // transpose tile, then Z[H]
     float* pw = fr + 2 * YS;                          // [H+1]
-    float* lm = pw + (H + 4);                         // [n_mel]
+    // stage 5 sees the wave's 4 frames as columns: lane (block b, column r)
+    float* wfr = s_frames + (size_t)(4 * wave) * per_frame;
+    const int blk = lane >> 2, col = lane & 3;
+    const float* pw_col = wfr + (size_t)col * per_frame + 2 * YS;
+    float* lm_col = wfr + (size_t)col * per_frame + 2 * YS + (H + 4);     // [4 kk]
+    float* part = wfr;                                // [16 blocks][4 columns][4]: over the dead tile
+    const int k0 = s_meta[blk];
+    const int grp_first = s_meta[16 + blk], grp_cnt = s_meta[32 + blk];   // (lane as (group, column))
+    const int ks = lane >> 4, cg = (lane >> 2) & 3;   // DCT: slice of filters, group of cepstra
 
     // twiddles of the register FFTs: W_P^q (first pass) and W_16^q (second pass)
     float2 twp[P / 2], tw16[8];
@@ -190,29 +222,39 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
         }
         return r;
     };
-    // Loads are unconditional (a predicated load costs a branch and a full wait):
-    // indices are clamped into the frame and the zero tail of the window table
-    // removes what the FFT must not see.  A group without a frame reads the start
-    // of the buffer and stores nothing.
-    auto fetch = [&](const Loc& l, float (&xr)[2 * P]) {
-        const float* x = audio + l.s0 + (int64_t)(l.t * hop);
-        const int lim = l.have ? c.n_used - 1
-                               : (int)(total - 1 < (int64_t)c.n_used - 1 ? total - 1 : c.n_used - 1);
+    // Sample loads are raw buffer loads on a per-chunk descriptor that ends with the
+    // packed buffer (a frame's 8-byte pairs are only 4-byte aligned; past the end the
+    // range check returns zeros).  All P rows of 32 samples are requested: what lies
+    // behind the frame's own samples meets the zero tail of the window table in a
+    // multiplication whose zero wins over anything (fmul_legacy), so a frame never
+    // sees its neighbour's samples.  A group without a frame reads the chunk's first
+    // samples and stores nothing.
+    auto fetch = [&](const Loc& l, int64_t bq, float (&xr)[2 * P]) {
+        const int64_t p0 = bq * chunk;
+        const uintptr_t a = (uintptr_t)(audio + p0);
+        const int64_t rest = (total - p0) * 4;
+        const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)a);
+        const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        const unsigned nrec = __builtin_amdgcn_readfirstlane((unsigned)(rest < 0xFFFFFF00ll ? rest : 0xFFFFFF00ll));
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((uintptr_t)hi32 << 32) | lo32), 0, nrec, 0x00020000);
+        const unsigned rel = l.have ? (unsigned)(l.s0 - p0) + l.t * hop : 0u;
+        const unsigned voff = (rel + 2u * (unsigned)j) * 4u;
 #pragma unroll
         for (int n1 = 0; n1 < P; ++n1) {
-            const int i0 = 32 * n1 + 2 * j;
-            xr[2 * n1] = x[min(i0, lim)];
-            xr[2 * n1 + 1] = x[min(i0 + 1, lim)];
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff + 128u * n1, 0, 0);
+            xr[2 * n1] = __uint_as_float(v[0]);
+            xr[2 * n1 + 1] = __uint_as_float(v[1]);
         }
     };
     Loc cur = locate(b_begin);
     float xc[2 * P];
-    fetch(cur, xc);
+    fetch(cur, b_begin, xc);
     for (int64_t b = b_begin; b < b_end; ++b) {
         Loc nxt = cur;
         float xn[2 * P];
         if (b + 1 < b_end) nxt = locate(b + 1);
-        fetch(nxt, xn);                           // (the last chunk's repeat is harmless)
+        fetch(nxt, b + 1 < b_end ? b + 1 : b, xn);   // (the last chunk's repeat is harmless)
         const bool have = cur.have;
         const unsigned t = cur.t, row0 = cur.row0;
         // ---- 1. window, bit-reversed register order, P-point FFT over n1
@@ -222,8 +264,8 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
         for (int n1 = 0; n1 < P; ++n1) {
             const int i0 = 32 * n1 + 2 * j;
             const float2 wv = *(const float2*)(s_win + i0);
-            re[brev(n1, ilog2(P))] = xc[2 * n1] * wv.x;
-            im[brev(n1, ilog2(P))] = xc[2 * n1 + 1] * wv.y;
+            re[brev(n1, ilog2(P))] = mul_zero_wins(xc[2 * n1], wv.x);
+            im[brev(n1, ilog2(P))] = mul_zero_wins(xc[2 * n1 + 1], wv.y);
         }
         if (any) {
         fft_regs<P>(re, im, twp);
@@ -279,26 +321,65 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
             pw[H / 2] = (z.x * z.x + z.y * z.y) * inv_n;
         }
         wave_sync();
-        // ---- mel triangles (contiguous runs), exact zeros -> eps, log_mult * log10
-        for (int m = j; m < c.n_mel; m += 16) {
-            const int q0 = s_melptr[m], q1 = s_melptr[m + 1], b0 = s_melstart[m];
-            float e = 0.f;
-            const float* pb = pw + b0 - q0;
-#pragma unroll 8
-            for (int q = q0; q < q1; ++q) e += pb[q] * s_melw[q];
-            if (e == 0.f) e = 2.220446049250313e-16f;
-            lm[m] = c.log_mult * __log10f(e);
+        // ---- 5. mel energies: block `blk` adds its range of bins for 4 filters x 4 frames
+        {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* wq = s_w4 + lane * 4;
+            const float* pq = pw_col + k0;
+            // (the next quad's operands are requested before this quad's products)
+            f32x4 w = *(const f32x4*)wq, pv = *(const f32x4*)pq;
+            for (int q = 0; q < c.nq; ++q) {
+                const int qn = q + 1 < c.nq ? q + 1 : q;
+                const f32x4 wn = *(const f32x4*)(wq + qn * 256);
+                const f32x4 pn = *(const f32x4*)(pq + qn * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w[e], pv[e], acc, 0, 0, 0);
+                w = wn;
+                pv = pn;
+            }
+            *(f32x4*)(part + lane * 4) = acc;
         }
         wave_sync();
-        // ---- DCT-II rows
-        if (have) {
-            float* dst = cep + (int64_t)(row0 + t) * c.n_ceps;
-            for (int k = j; k < c.n_ceps; k += 16) {
-                float acc = 0.f;
-                const float* row = s_dct + k * drow;
-#pragma unroll 8
-                for (int m = 0; m < c.n_mel; ++m) acc += row[m] * lm[m];
-                dst[k] = acc;
+        // blocks of one group of filters add up; exact zeros -> eps; log_mult * log10
+        if (blk < c.groups) {
+            f32x4 e = {0.f, 0.f, 0.f, 0.f};
+            for (int nb = grp_first; nb < grp_first + grp_cnt; ++nb) e += *(const f32x4*)(part + (nb * 4 + col) * 4);
+            f32x4 l;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = e[i] == 0.f ? 2.220446049250313e-16f : e[i];
+                l[i] = c.log_mult * __log10f(v);
+            }
+            *(f32x4*)(lm_col + 4 * blk) = l;
+        }
+        wave_sync();
+        // ---- DCT-II rows: 4 cepstra x 4 frames per block, over one slice of the filters
+        {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* aq = s_dctA + lane * c.kk;
+            const float* bq = lm_col + ks * c.kk;
+            f32x4 a = *(const f32x4*)aq, bv = *(const f32x4*)bq;
+            for (int q = 0; q < c.kk; q += 4) {
+                const int qn = q + 4 < c.kk ? q + 4 : q;
+                const f32x4 an = *(const f32x4*)(aq + qn);
+                const f32x4 bn = *(const f32x4*)(bq + qn);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[e], bv[e], acc, 0, 0, 0);
+                a = an;
+                bv = bn;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = sum_rows(acc[i]);
+            // the frame of column `col` belongs to lane group `col` of the FFT stages
+            const int rowi = have ? (int)(row0 + t) : -1;
+            const int r0 = __builtin_amdgcn_readlane(rowi, 0), r1 = __builtin_amdgcn_readlane(rowi, 16);
+            const int r2 = __builtin_amdgcn_readlane(rowi, 32), r3 = __builtin_amdgcn_readlane(rowi, 48);
+            const int rc = col == 0 ? r0 : col == 1 ? r1 : col == 2 ? r2 : r3;
+            if (ks == 0 && rc >= 0) {
+                float* dst = cep + (int64_t)rc * c.n_ceps + 4 * cg;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (4 * cg + i < c.n_ceps) dst[i] = acc[i];
             }
         }
         wave_sync();
@@ -315,12 +396,9 @@ template <int P>
 int launch_fast(srx_context* h, const float* audio, const int64_t* so, int64_t U, int64_t total,
                 const FastDev& d, float* cep, hipStream_t st) {
     constexpr int H = 16 * P, N = 2 * H, YS = P * 17;
-    const int lpad = N, wpad = (d.nnz + 3) & ~3;
-    const int mpad = (d.n_mel + 3) & ~3;
     const size_t tables = sizeof(float2) * N + sizeof(float2) * P * 16 +
-                          4 * ((size_t)lpad + wpad + ((d.n_mel + 1 + 3) & ~3) + mpad +
-                               ((d.n_ceps * (d.n_mel + 1) + 3) & ~3));
-    const size_t per_frame = 4 * ((size_t)2 * YS + (H + 4) + mpad);
+                          4 * ((size_t)N + (size_t)d.nq * 256 + 64 * (size_t)d.kk + 48);
+    const size_t per_frame = 4 * ((size_t)2 * YS + (H + 4) + 4 * (size_t)d.kk);
     const size_t lds = tables + per_frame * kFramesPerBlock;
     if (lds > 160 * 1024) return SRX_EUNSUPPORTED;
     auto kern = cepstra_fast_kernel<P>;
@@ -339,17 +417,16 @@ int launch_fast(srx_context* h, const float* audio, const int64_t* so, int64_t U
 int srx_mfcc_fast_cepstra(srx_context* h, srx_mfcc_plan* p, const float* audio, const int64_t* so,
                           int64_t U, int64_t total, float* cep, hipStream_t st) {
     const srx_mfcc_cfg_t& c = p->cfg;
-    if (!p->fast_ok || (c.nfft != 512 && c.nfft != 1024) || total >= 0xFFFFFFFFll) return SRX_EUNSUPPORTED;
+    if (!p->mm_ok || (c.nfft != 512 && c.nfft != 1024) || total >= 0xFFFFFFFFll) return SRX_EUNSUPPORTED;
     FastDev d;
     d.frame_len = c.frame_len; d.hop = c.hop;
     d.n_used = c.frame_len < c.nfft ? c.frame_len : c.nfft;
     d.n_mel = c.n_mel; d.n_ceps = c.n_ceps; d.nnz = p->nnz;
+    d.nq = p->mm_nq; d.kk = p->mm_kk; d.groups = p->mm_groups;
+    d.mm_w = (const float*)p->mm_w; d.mm_dct = (const float*)p->mm_dct; d.mm_meta = p->mm_meta;
     d.log_mult = (float)c.log_mult;
     d.window = (const float*)p->window[0];
     d.tw = (const float2*)p->tw_full;
-    d.mel_ptr = p->mel_ptr; d.mel_start = p->mel_start;
-    d.mel_w = (const float*)p->mel_w[0];
-    d.dct = (const float*)p->dct[0];
     return c.nfft == 512 ? launch_fast<16>(h, audio, so, U, total, d, cep, st)
                          : launch_fast<32>(h, audio, so, U, total, d, cep, st);
 }

@@ -44,6 +44,11 @@ struct srx_mfcc_plan {
     void* tw_full;         // [nfft] complex exp(-2 pi i k / nfft)
     int32_t* mel_start;    // [n_mel] first bin of each filter
     int fast_ok;           // every filter is one contiguous run of bins
+    // mel / DCT stages of that kernel as 4x4 matrix-core blocks (see mfcc_fast.hip)
+    void* mm_w;            // [mm_nq][64][4] mel weights per (quad of bins, lane)
+    void* mm_dct;          // [64][mm_kk] DCT coefficients per lane
+    int32_t* mm_meta;      // [16] first bin of a block, [16] first block and [16] block count of a filter group
+    int mm_nq, mm_kk, mm_groups, mm_ok;
 };
 
 void srx_set_error(const char* fmt, ...);
