@@ -292,6 +292,182 @@ __global__ void finish_kernel(const T* __restrict__ cep, const int64_t* __restri
     }
 }
 
+// The same stage for delta_n = N known at compile time, without the delta blocks
+// in LDS: a workgroup stages a tile of the utterance's cepstra (plus 2N rows either
+// side), thread (coefficient k, row segment) walks down its rows with the 2N+1
+// first-order deltas around the current row in registers -- one new delta (2N LDS
+// reads) per row -- and emits the row's c, delta and delta-delta.  The walk is
+// repeated for the column means, the column variances and the write; only the
+// tile is re-read from global memory, and only when the utterance has several.
+// Summation orders are those of finish_kernel.
+template <typename T, int N>
+__global__ __launch_bounds__(256) void finish_stream_kernel(
+    const T* __restrict__ cep, const int64_t* __restrict__ so, const int64_t* __restrict__ fo,
+    int64_t U, MfccDev c, int order, int zscore, int tile_rows, T* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fin_raw[];
+    T* tile = (T*)fin_raw;                      // [tile_rows + 4N][K]
+    __shared__ double red[3 * 256];
+    __shared__ T col_mean[128], col_scale[128];
+    const int K = c.n_ceps, NF = K * (1 + order);
+    const int nseg = blockDim.x / K, k = threadIdx.x % K, seg = threadIdx.x / K;
+    int den = 0;
+    for (int i = 1; i <= N; ++i) den += 2 * i * i;
+    const T inv_den = (T)1 / (T)den;
+    for (int64_t u = blockIdx.x; u < U; u += gridDim.x) {
+        const int64_t s0 = so[u], n = so[u + 1] - s0;
+        const int64_t Tu = raw_frames(n, c.frame_len, c.hop);
+        const int trim = order > 0 ? N : 0;
+        const int64_t To = Tu - 2 * trim > 0 ? Tu - 2 * trim : 0;
+        if (To == 0) continue;
+        const T* cu = cep + (s0 / c.hop) * K;
+        T* ou = out + fo[u] * NF;
+        const int64_t n_tiles = (To + tile_rows - 1) / tile_rows;
+        if (threadIdx.x < NF) {
+            col_mean[threadIdx.x] = (T)0;
+            col_scale[threadIdx.x] = (T)1;
+        }
+        const int first = zscore ? 0 : 2;
+        for (int phase = first; phase < 3; ++phase) {
+            double acc[3] = {0.0, 0.0, 0.0};
+            T mean[3], inv[3];
+            __syncthreads();                    // col_mean / col_scale of the previous phase
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                mean[o] = o <= order ? col_mean[o * K + k] : (T)0;
+                inv[o] = o <= order ? (T)1 / col_scale[o * K + k] : (T)1;
+            }
+            for (int64_t ti = 0; ti < n_tiles; ++ti) {
+                const int64_t t0 = trim + ti * tile_rows;
+                const int64_t t1 = t0 + tile_rows < Tu - trim ? t0 + tile_rows : Tu - trim;
+                const int64_t lo = t0 - 2 * N > 0 ? t0 - 2 * N : 0;
+                const int64_t hi = t1 + 2 * N < Tu ? t1 + 2 * N : Tu;
+                if (n_tiles > 1 || phase == first) {
+                    __syncthreads();            // walkers of the previous tile
+                    const int cnt = (int)(hi - lo) * K;
+                    const T* src = cu + lo * K;
+                    // (8 loads in flight per thread: one at a time, the copy would take
+                    // a memory round trip per 256 elements)
+                    for (int i0 = threadIdx.x; i0 < cnt; i0 += 8 * blockDim.x) {
+                        T v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int i = i0 + q * blockDim.x;
+                            v[q] = i < cnt ? src[i] : (T)0;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int i = i0 + q * blockDim.x;
+                            if (i < cnt) tile[i] = v[q];
+                        }
+                    }
+                    __syncthreads();
+                }
+                if (seg >= nseg) continue;
+                const int64_t per = (t1 - t0 + nseg - 1) / nseg;
+                const int64_t a = t0 + seg * per;
+                const int64_t b = a + per < t1 ? a + per : t1;
+                if (a >= b) continue;
+                // (32-bit row numbers relative to the tile: a clamp is one instruction)
+                const T* col = tile + k;
+                const int r_lo = (int)(0 - lo), r_hi = (int)(Tu - 1 - lo);   // rows 0 and Tu-1
+                auto d1 = [&](int s) {
+                    s = min(max(s, r_lo), r_hi);
+                    T v = 0;
+#pragma unroll
+                    for (int j = -N; j <= N; ++j) {
+                        if (j == 0) continue;
+                        const int tt = min(max(s + j, r_lo), r_hi);
+                        v += (T)j * col[tt * K];
+                    }
+                    return v * inv_den;
+                };
+                const int ra = (int)(a - lo), rb = (int)(b - lo);
+                T* orow = ou + (a - trim) * NF + k;
+                T w[2 * N + 1];
+#pragma unroll
+                for (int i = 0; i <= 2 * N; ++i) w[i] = (T)0;
+                if (order >= 2) {
+#pragma unroll
+                    for (int i = 0; i < 2 * N; ++i) w[i + 1] = d1(ra - N + i);
+                } else if (order == 1) {
+                    w[N + 1] = d1(ra);          // (becomes the centre after the first shift)
+                }
+                for (int t = ra; t < rb; ++t) {
+                    T v[3];
+                    v[0] = col[t * K];
+#pragma unroll
+                    for (int i = 0; i < 2 * N; ++i) w[i] = w[i + 1];
+                    if (order >= 2) {
+                        w[2 * N] = d1(t + N);
+                        T a2 = 0;
+#pragma unroll
+                        for (int i = -N; i <= N; ++i) a2 += (T)i * w[N + i];
+                        v[2] = a2 * inv_den;
+                    } else {
+                        v[2] = (T)0;
+                        if (order == 1) w[N + 1] = d1(t + 1);
+                    }
+                    v[1] = w[N];
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) {
+                        if (o > order) continue;
+                        if (phase == 0) {
+                            acc[o] += (double)v[o];
+                        } else if (phase == 1) {
+                            const double d = (double)v[o] - (double)mean[o];
+                            acc[o] += d * d;
+                        } else {
+                            orow[o * K] = (v[o] - mean[o]) * inv[o];
+                        }
+                    }
+                    orow += NF;
+                }
+            }
+            if (phase == 2) break;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) red[o * 256 + threadIdx.x] = seg < nseg ? acc[o] : 0.0;
+            __syncthreads();
+            if (threadIdx.x < NF) {
+                const int o = threadIdx.x / K, kk = threadIdx.x % K;
+                double s = 0.0;
+                for (int g = 0; g < nseg; ++g) s += red[o * 256 + g * K + kk];
+                if (phase == 0) {
+                    col_mean[threadIdx.x] = (T)(s / (double)To);
+                } else {
+                    const T var = (T)(s / (double)To);
+                    const T mu = col_mean[threadIdx.x];
+                    const T e = eps_of<T>();
+                    const T bound = (T)To * e * var + ((T)To * mu * e) * ((T)To * mu * e);
+                    T sc = sqrt(var);
+                    if (var <= bound || sc == (T)0) sc = (T)1;   // constant column keeps scale 1
+                    col_scale[threadIdx.x] = sc;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Launches finish_stream_kernel when delta_n has an instantiation; false otherwise.
+template <typename T>
+bool launch_finish_stream(srx_context* h, const void* cep, const int64_t* so, const int64_t* fo,
+                          int64_t U, const MfccDev& d, const srx_mfcc_cfg_t& c, void* out,
+                          hipStream_t st) {
+    const int N = c.delta_order > 0 ? c.delta_n : 1;
+    if (N > 3) return false;
+    const size_t lds = 16 * 1024;
+    const int rows = (int)(lds / (sizeof(T) * (size_t)c.n_ceps)) - 4 * N;
+    if (rows < 16) return false;
+    int64_t grid = U < (int64_t)h->n_cu * 64 ? U : (int64_t)h->n_cu * 64;
+#define SRX_CASE(n)                                                                              \
+    if (N == n)                                                                                  \
+        hipLaunchKernelGGL((finish_stream_kernel<T, n>), dim3((unsigned)grid), dim3(256), lds, st, \
+                           (const T*)cep, so, fo, U, d, c.delta_order, c.zscore, rows, (T*)out);
+    SRX_CASE(1) SRX_CASE(2) SRX_CASE(3)
+#undef SRX_CASE
+    return true;
+}
+
 template <typename T>
 int upload(const std::vector<double>& v, void** dst) {
     std::vector<T> tmp(v.begin(), v.end());
@@ -575,9 +751,10 @@ int srx_mfcc_batch(srx_handle_t h, srx_mfcc_plan_t p, const void* audio, int dty
                            n_samples, d, (const double*)p->window[idx],
                            (const cplx<double>*)p->twiddle[idx], (const double*)p->mel_w[idx],
                            (const double*)p->dct[idx], (double*)cep);
-        hipLaunchKernelGGL(finish_kernel<double>, dim3((unsigned)grid2), dim3(256), fin_lds, st,
-                           (const double*)cep, sample_offsets, frame_offsets, n_utts, d,
-                           c.delta_order, c.delta_n, c.zscore, fin_elems, (double*)out_feats);
+        if (!launch_finish_stream<double>(h, cep, sample_offsets, frame_offsets, n_utts, d, c, out_feats, st))
+            hipLaunchKernelGGL(finish_kernel<double>, dim3((unsigned)grid2), dim3(256), fin_lds, st,
+                               (const double*)cep, sample_offsets, frame_offsets, n_utts, d,
+                               c.delta_order, c.delta_n, c.zscore, fin_elems, (double*)out_feats);
     } else {
         rc = h->exact_f32 ? SRX_EUNSUPPORTED
                           : srx_mfcc_fast_cepstra(h, p, (const float*)audio, sample_offsets, n_utts,
@@ -590,9 +767,10 @@ int srx_mfcc_batch(srx_handle_t h, srx_mfcc_plan_t p, const void* audio, int dty
                                (const float*)p->dct[idx], (float*)cep);
         else if (rc)
             return rc;
-        hipLaunchKernelGGL(finish_kernel<float>, dim3((unsigned)grid2), dim3(256), fin_lds, st,
-                           (const float*)cep, sample_offsets, frame_offsets, n_utts, d,
-                           c.delta_order, c.delta_n, c.zscore, fin_elems, (float*)out_feats);
+        if (!launch_finish_stream<float>(h, cep, sample_offsets, frame_offsets, n_utts, d, c, out_feats, st))
+            hipLaunchKernelGGL(finish_kernel<float>, dim3((unsigned)grid2), dim3(256), fin_lds, st,
+                               (const float*)cep, sample_offsets, frame_offsets, n_utts, d,
+                               c.delta_order, c.delta_n, c.zscore, fin_elems, (float*)out_feats);
     }
     SRX_HIP(hipGetLastError());
     return SRX_OK;

@@ -112,30 +112,31 @@ __device__ __forceinline__ int64_t raw_frames(int64_t n, int L, int hop) {
 }
 
 template <int P>
-__global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
+__global__ __launch_bounds__(256, P == 16 ? 3 : 1) void cepstra_fast_kernel(
     const float* __restrict__ audio, const int64_t* __restrict__ so, int64_t U, int64_t total,
     FastDev c, float* __restrict__ cep) {
     constexpr int H = 16 * P, N = 2 * H, KB = P / 16;   // KB 16-point FFTs per lane in step 3
     constexpr int YS = P * 17;                          // float2 per frame in the transpose tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // ---- shared tables
-    float2* s_tw = (float2*)smem_raw;                       // [N]
-    float* s_win = (float*)(s_tw + N);                      // [N], zero past the samples the FFT uses
-    const int lpad = N;
-    float* s_w4 = s_win + lpad;                             // [nq][64][4]
+    float2* s_tw = (float2*)smem_raw;                       // [H/2]: exp(-2 pi i k / N)
+    float* s_win = (float*)(s_tw + H / 2);                  // [N], zero past the samples the FFT uses
+    float* s_w4 = s_win + N;                                // [nq][64][4]
     float* s_dctA = s_w4 + (size_t)c.nq * 256;              // [64][kk]
     int* s_meta = (int*)(s_dctA + 64 * c.kk);               // [48]
     float2* s_tw2 = (float2*)(s_meta + 48);                 // [P][16]: W_H^(j k1)
     float* s_frames = (float*)(s_tw2 + P * 16);
-    const int per_frame = 2 * YS + (H + 4) + 4 * c.kk;      // floats
-    for (int i = threadIdx.x; i < N; i += blockDim.x) s_tw[i] = c.tw[i];
+    // A frame's tile holds the transpose buffer Y / the spectrum Z first; once Z has
+    // been read, the same floats hold pw [H+4], the log-mel row [4 kk] and a quarter
+    // of the wave's partial mel sums [64].
+    constexpr int per_frame = 2 * YS;                       // floats
+    constexpr int kPw = 0, kLm = H + 4;
+    const int part_off = kLm + 4 * c.kk;
+    for (int i = threadIdx.x; i < H / 2; i += blockDim.x) s_tw[i] = c.tw[i];
     for (int i = threadIdx.x; i < N; i += blockDim.x) s_win[i] = i < c.n_used ? c.window[i] : 0.f;
     for (int i = threadIdx.x; i < c.nq * 256; i += blockDim.x) s_w4[i] = c.mm_w[i];
     for (int i = threadIdx.x; i < 64 * c.kk; i += blockDim.x) s_dctA[i] = c.mm_dct[i];
     for (int i = threadIdx.x; i < 48; i += blockDim.x) s_meta[i] = c.mm_meta[i];
-    // the padding behind the power spectra and the log-mel rows meets zero weights:
-    // it must hold finite numbers
-    for (int i = threadIdx.x; i < kFramesPerBlock * per_frame; i += blockDim.x) s_frames[i] = 0.f;
     for (int i = threadIdx.x; i < P * 16; i += blockDim.x)
         s_tw2[i] = c.tw[2 * (((i & 15) * (i >> 4)) & (H - 1))];
     __syncthreads();
@@ -145,13 +146,16 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
     const int item = 4 * wave + fs;                   // frame slot in the workgroup
     float* fr = s_frames + (size_t)item * per_frame;
     float2* Y = (float2*)fr;                          // transpose tile, then Z[H]
-    float* pw = fr + 2 * YS;                          // [H+1]
+    float* pw = fr + kPw;                             // [H+1] (+3 of padding)
     // stage 5 sees the wave's 4 frames as columns: lane (block b, column r)
     float* wfr = s_frames + (size_t)(4 * wave) * per_frame;
     const int blk = lane >> 2, col = lane & 3;
-    const float* pw_col = wfr + (size_t)col * per_frame + 2 * YS;
-    float* lm_col = wfr + (size_t)col * per_frame + 2 * YS + (H + 4);     // [4 kk]
-    float* part = wfr;                                // [16 blocks][4 columns][4]: over the dead tile
+    const float* pw_col = wfr + (size_t)col * per_frame + kPw;
+    float* lm_col = wfr + (size_t)col * per_frame + kLm;                  // [4 kk]
+    // partial sums of block b, column r: 4 floats in the tile of frame b / 4
+    auto part_at = [&](int b, int r) {
+        return wfr + (size_t)(b >> 2) * per_frame + part_off + (b & 3) * 16 + r * 4;
+    };
     const int k0 = s_meta[blk];
     const int grp_first = s_meta[16 + blk], grp_cnt = s_meta[32 + blk];   // (lane as (group, column))
     const int ks = lane >> 4, cg = (lane >> 2) & 3;   // DCT: slice of filters, group of cepstra
@@ -159,9 +163,9 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
     // twiddles of the register FFTs: W_P^q (first pass) and W_16^q (second pass)
     float2 twp[P / 2], tw16[8];
 #pragma unroll
-    for (int q = 0; q < P / 2; ++q) twp[q] = s_tw[q * (N / P)];
+    for (int q = 0; q < P / 2; ++q) twp[q] = c.tw[q * (N / P)];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) tw16[q] = s_tw[q * (N / 16)];
+    for (int q = 0; q < 8; ++q) tw16[q] = c.tw[q * (N / 16)];
 
     // A workgroup walks a CONTIGUOUS range of chunks: the utterance under its
     // position then advances monotonically (offsets cached in registers, no search
@@ -301,10 +305,19 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
         wave_sync();
         // ---- 4. real-input spectrum, power / N.  Bins k and H-k share their inputs.
         const float inv_n = 1.0f / (float)N;
+        float2 zks[P / 2], zcs[P / 2];
 #pragma unroll
         for (int mm = 0; mm < P / 2; ++mm) {
             const int k = j + 16 * mm;            // 0 .. H/2-1 ; partner H-k
-            const float2 zk = Y[k], zc = Y[(H - k) & (H - 1)];
+            zks[mm] = Y[k];
+            zcs[mm] = Y[(H - k) & (H - 1)];
+        }
+        const float2 zh = Y[H / 2];
+        wave_sync();                              // Z is in registers: pw may take its place
+#pragma unroll
+        for (int mm = 0; mm < P / 2; ++mm) {
+            const int k = j + 16 * mm;
+            const float2 zk = zks[mm], zc = zcs[mm];
             const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
             const float orr = 0.5f * (zk.y + zc.y), oi = -0.5f * (zk.x - zc.x);
             const float2 w = s_tw[k];
@@ -315,11 +328,10 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
             pw[k] = (xr * xr + xi * xi) * inv_n;
             pw[H - k] = (yr * yr + yi * yi) * inv_n;
         }
-        if (j == 0) {   // k = H/2 is its own partner
-            const float2 z = Y[H / 2];
-            // E = (zr, 0), O = (zi, 0) for the self-paired bin; W^(H/2) = -i
-            pw[H / 2] = (z.x * z.x + z.y * z.y) * inv_n;
+        if (j == 0) {   // k = H/2 is its own partner: E = (zr, 0), O = (zi, 0), W^(H/2) = -i
+            pw[H / 2] = (zh.x * zh.x + zh.y * zh.y) * inv_n;
         }
+        if (j < 3) pw[H + 1 + j] = 0.f;           // padding that meets zero weights: keep it finite
         wave_sync();
         // ---- 5. mel energies: block `blk` adds its range of bins for 4 filters x 4 frames
         {
@@ -337,13 +349,13 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
                 w = wn;
                 pv = pn;
             }
-            *(f32x4*)(part + lane * 4) = acc;
+            *(f32x4*)part_at(blk, col) = acc;
         }
         wave_sync();
         // blocks of one group of filters add up; exact zeros -> eps; log_mult * log10
         if (blk < c.groups) {
             f32x4 e = {0.f, 0.f, 0.f, 0.f};
-            for (int nb = grp_first; nb < grp_first + grp_cnt; ++nb) e += *(const f32x4*)(part + (nb * 4 + col) * 4);
+            for (int nb = grp_first; nb < grp_first + grp_cnt; ++nb) e += *(const f32x4*)part_at(nb, col);
             f32x4 l;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -351,6 +363,8 @@ __global__ __launch_bounds__(256, 2) void cepstra_fast_kernel(
                 l[i] = c.log_mult * __log10f(v);
             }
             *(f32x4*)(lm_col + 4 * blk) = l;
+        } else if (blk < c.kk) {
+            *(f32x4*)(lm_col + 4 * blk) = f32x4{0.f, 0.f, 0.f, 0.f};      // padding of the log-mel row
         }
         wave_sync();
         // ---- DCT-II rows: 4 cepstra x 4 frames per block, over one slice of the filters
@@ -396,16 +410,23 @@ template <int P>
 int launch_fast(srx_context* h, const float* audio, const int64_t* so, int64_t U, int64_t total,
                 const FastDev& d, float* cep, hipStream_t st) {
     constexpr int H = 16 * P, N = 2 * H, YS = P * 17;
-    const size_t tables = sizeof(float2) * N + sizeof(float2) * P * 16 +
+    const size_t tables = sizeof(float2) * (H / 2) + sizeof(float2) * P * 16 +
                           4 * ((size_t)N + (size_t)d.nq * 256 + 64 * (size_t)d.kk + 48);
-    const size_t per_frame = 4 * ((size_t)2 * YS + (H + 4) + 4 * (size_t)d.kk);
+    const size_t per_frame = 4 * (size_t)2 * YS;
+    if ((size_t)(H + 4) + 4 * (size_t)d.kk + 64 > (size_t)2 * YS) return SRX_EUNSUPPORTED;
     const size_t lds = tables + per_frame * kFramesPerBlock;
+
     if (lds > 160 * 1024) return SRX_EUNSUPPORTED;
     auto kern = cepstra_fast_kernel<P>;
     SRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t chunk = (int64_t)kFramesPerBlock * d.hop;
     const int64_t n_chunks = (total + chunk - 1) / chunk;
-    int64_t grid = n_chunks < (int64_t)h->n_cu * 4 ? n_chunks : (int64_t)h->n_cu * 4;
+    // four rounds of the workgroups that fit a CU at once (LDS decides)
+    int per_cu = (int)((160 * 1024) / lds);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
+    if (P != 16) per_cu = 1;
+    const int64_t want = (int64_t)h->n_cu * per_cu * 4;
+    int64_t grid = n_chunks < want ? n_chunks : want;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, audio, so, U, total, d, cep);
     SRX_HIP(hipGetLastError());

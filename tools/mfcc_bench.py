@@ -5,7 +5,9 @@ ctx = sra.Context.default(0)
 n_utt, n_samp = 8192, 48000
 audio = 0.2 * torch.randn((n_utt * n_samp,), device='cuda', dtype=torch.float32)
 so = np.arange(0, (n_utt + 1) * n_samp, n_samp, dtype=np.int64)
-plan = sra.MfccPlan(ctx, 16000, nfft=512, n_mel=40, delta_order=2, zscore=True)
+order = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+zs = (sys.argv[2] != "0") if len(sys.argv) > 2 else True
+plan = sra.MfccPlan(ctx, 16000, nfft=512, n_mel=40, delta_order=order, zscore=zs)
 feats, fo = plan.run(audio, so)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
