@@ -35,6 +35,7 @@ struct FastDev {
     float log_mult;
     const float* window;      // [frame_len]
     const float2* tw;         // [N] exp(-2 pi i k / N)
+    unsigned hop_m, hop_s;    // n / hop = umulhi(n, hop_m) >> hop_s for n < 2^31
     int nq, kk, groups;       // quads of bins per block, filters per DCT slice, groups of 4 filters
     const float* mm_w;        // [nq][64][4]
     const float* mm_dct;      // [64][kk]
@@ -74,10 +75,20 @@ constexpr int brev(int i, int bits) {
     return r;
 }
 
+// Complex numbers are (re, im) register pairs so that additions and the two halves
+// of a complex product are packed-f32 instructions.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f cmul(v2f w, v2f z) {
+    // (w.x z.x - w.y z.y, w.x z.y + w.y z.x)
+    const v2f wyy = {-w.y, w.y};
+    return w.xx * z + wyy * z.yx;
+}
+
 // In-place radix-2 DIT on registers.  Input must already sit in bit-reversed
 // order (a[brev(n)] = x[n]); tw[q] = W_Q^q for q < Q/2.
 template <int Q>
-__device__ __forceinline__ void fft_regs(float (&re)[Q], float (&im)[Q], const float2 (&tw)[Q / 2]) {
+__device__ __forceinline__ void fft_regs(v2f (&z)[Q], const v2f (&tw)[Q / 2]) {
 #pragma unroll
     for (int s = 1; s <= ilog2(Q); ++s) {
         const int m = 1 << s, half = m >> 1, tstep = Q / m;
@@ -86,22 +97,16 @@ __device__ __forceinline__ void fft_regs(float (&re)[Q], float (&im)[Q], const f
 #pragma unroll
             for (int jj = 0; jj < half; ++jj) {
                 const int i0 = k + jj, i1 = i0 + half;
-                float tr, ti;
+                v2f t;
                 if (jj == 0) {
-                    tr = re[i1];
-                    ti = im[i1];
+                    t = z[i1];
                 } else if (2 * jj == half) {     // W = -i
-                    tr = im[i1];
-                    ti = -re[i1];
+                    t = v2f{z[i1].y, -z[i1].x};
                 } else {
-                    const float2 w = tw[jj * tstep];
-                    tr = w.x * re[i1] - w.y * im[i1];
-                    ti = w.x * im[i1] + w.y * re[i1];
+                    t = cmul(tw[jj * tstep], z[i1]);
                 }
-                re[i1] = re[i0] - tr;
-                im[i1] = im[i0] - ti;
-                re[i0] += tr;
-                im[i0] += ti;
+                z[i1] = z[i0] - t;
+                z[i0] = z[i0] + t;
             }
         }
     }
@@ -119,12 +124,12 @@ __global__ __launch_bounds__(256, P == 16 ? 3 : 1) void cepstra_fast_kernel(
     constexpr int YS = P * 17;                          // float2 per frame in the transpose tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // ---- shared tables
-    float2* s_tw = (float2*)smem_raw;                       // [H/2]: exp(-2 pi i k / N)
+    v2f* s_tw = (v2f*)smem_raw;                       // [H/2]: exp(-2 pi i k / N)
     float* s_win = (float*)(s_tw + H / 2);                  // [N], zero past the samples the FFT uses
     float* s_w4 = s_win + N;                                // [nq][64][4]
     float* s_dctA = s_w4 + (size_t)c.nq * 256;              // [64][kk]
     int* s_meta = (int*)(s_dctA + 64 * c.kk);               // [48]
-    float2* s_tw2 = (float2*)(s_meta + 48);                 // [P][16]: W_H^(j k1)
+    v2f* s_tw2 = (v2f*)(s_meta + 48);                 // [P][16]: W_H^(j k1)
     float* s_frames = (float*)(s_tw2 + P * 16);
     // A frame's tile holds the transpose buffer Y / the spectrum Z first; once Z has
     // been read, the same floats hold pw [H+4], the log-mel row [4 kk] and a quarter
@@ -132,20 +137,23 @@ __global__ __launch_bounds__(256, P == 16 ? 3 : 1) void cepstra_fast_kernel(
     constexpr int per_frame = 2 * YS;                       // floats
     constexpr int kPw = 0, kLm = H + 4;
     const int part_off = kLm + 4 * c.kk;
-    for (int i = threadIdx.x; i < H / 2; i += blockDim.x) s_tw[i] = c.tw[i];
+    for (int i = threadIdx.x; i < H / 2; i += blockDim.x) s_tw[i] = v2f{c.tw[i].x, c.tw[i].y};
     for (int i = threadIdx.x; i < N; i += blockDim.x) s_win[i] = i < c.n_used ? c.window[i] : 0.f;
     for (int i = threadIdx.x; i < c.nq * 256; i += blockDim.x) s_w4[i] = c.mm_w[i];
     for (int i = threadIdx.x; i < 64 * c.kk; i += blockDim.x) s_dctA[i] = c.mm_dct[i];
     for (int i = threadIdx.x; i < 48; i += blockDim.x) s_meta[i] = c.mm_meta[i];
     for (int i = threadIdx.x; i < P * 16; i += blockDim.x)
-        s_tw2[i] = c.tw[2 * (((i & 15) * (i >> 4)) & (H - 1))];
+    {
+        const float2 w = c.tw[2 * (((i & 15) * (i >> 4)) & (H - 1))];
+        s_tw2[i] = v2f{w.x, w.y};
+    }
     __syncthreads();
 
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int fs = lane >> 4, j = lane & 15;          // frame slot in the wave, lane in the group
     const int item = 4 * wave + fs;                   // frame slot in the workgroup
     float* fr = s_frames + (size_t)item * per_frame;
-    float2* Y = (float2*)fr;                          // transpose tile, then Z[H]
+    v2f* Y = (v2f*)fr;                          // transpose tile, then Z[H]
     float* pw = fr + kPw;                             // [H+1] (+3 of padding)
     // stage 5 sees the wave's 4 frames as columns: lane (block b, column r)
     float* wfr = s_frames + (size_t)(4 * wave) * per_frame;
@@ -161,11 +169,11 @@ __global__ __launch_bounds__(256, P == 16 ? 3 : 1) void cepstra_fast_kernel(
     const int ks = lane >> 4, cg = (lane >> 2) & 3;   // DCT: slice of filters, group of cepstra
 
     // twiddles of the register FFTs: W_P^q (first pass) and W_16^q (second pass)
-    float2 twp[P / 2], tw16[8];
+    v2f twp[P / 2], tw16[8];
 #pragma unroll
-    for (int q = 0; q < P / 2; ++q) twp[q] = c.tw[q * (N / P)];
+    for (int q = 0; q < P / 2; ++q) twp[q] = v2f{c.tw[q * (N / P)].x, c.tw[q * (N / P)].y};
 #pragma unroll
-    for (int q = 0; q < 8; ++q) tw16[q] = c.tw[q * (N / 16)];
+    for (int q = 0; q < 8; ++q) tw16[q] = v2f{c.tw[q * (N / 16)].x, c.tw[q * (N / 16)].y};
 
     // A workgroup walks a CONTIGUOUS range of chunks: the utterance under its
     // position then advances monotonically (offsets cached in registers, no search
@@ -188,13 +196,16 @@ __global__ __launch_bounds__(256, P == 16 ? 3 : 1) void cepstra_fast_kernel(
     }
     int64_t so_lo = so[lo], so_nx = so[lo + 1];
     const unsigned hop = (unsigned)c.hop;
+    // division by the hop as a multiplication (exact below 2^31; the values are
+    // wave-uniform, so this stays on the scalar unit)
+    auto div_hop = [&](unsigned n) { return __umulhi(n, c.hop_m) >> c.hop_s; };
     struct Loc {
         bool have;
         int64_t s0;
         unsigned t, row0;
     };
     // which frame does this lane group own?  (item-th frame starting in [p0, p1))
-    // The packed buffer holds < 2^32 samples here, so 32-bit division is enough.
+    // The packed buffer holds < 2^31 samples here: 32-bit arithmetic is enough.
     auto locate = [&](int64_t bq) {
         const int64_t p0 = bq * chunk;
         const int64_t p1 = p0 + chunk < total ? p0 + chunk : total;
@@ -208,17 +219,17 @@ __global__ __launch_bounds__(256, P == 16 ? 3 : 1) void cepstra_fast_kernel(
         int64_t us = so_lo, ue = so_nx;
         for (int64_t u = lo; u < U && us < p1 && !r.have; ++u) {
             const unsigned n = (unsigned)(ue - us);
-            const unsigned Tu = n < (unsigned)c.frame_len ? 0u : (n - (unsigned)c.frame_len) / hop + 1u;
+            const unsigned Tu = n < (unsigned)c.frame_len ? 0u : div_hop(n - (unsigned)c.frame_len) + 1u;
             const unsigned a = p0 > us ? (unsigned)(p0 - us) : 0u;
-            const unsigned ta = (a + hop - 1u) / hop;
-            unsigned tb = ((unsigned)(p1 - us) + hop - 1u) / hop;
+            const unsigned ta = div_hop(a + hop - 1u);
+            unsigned tb = div_hop((unsigned)(p1 - us) + hop - 1u);
             if (tb > Tu) tb = Tu;
             const int nn = tb > ta ? (int)(tb - ta) : 0;
             if (item < cnt + nn) {
                 r.have = true;
                 r.s0 = us;
                 r.t = ta + (unsigned)(item - cnt);
-                r.row0 = (unsigned)us / hop;
+                r.row0 = div_hop((unsigned)us);
             }
             cnt += nn;
             us = ue;
@@ -263,73 +274,63 @@ __global__ __launch_bounds__(256, P == 16 ? 3 : 1) void cepstra_fast_kernel(
         const unsigned t = cur.t, row0 = cur.row0;
         // ---- 1. window, bit-reversed register order, P-point FFT over n1
         const bool any = __ballot(have) != 0;     // no frame starts in this chunk for this wave?
-        float re[P], im[P];
+        v2f z1[P];
 #pragma unroll
         for (int n1 = 0; n1 < P; ++n1) {
             const int i0 = 32 * n1 + 2 * j;
             const float2 wv = *(const float2*)(s_win + i0);
-            re[brev(n1, ilog2(P))] = mul_zero_wins(xc[2 * n1], wv.x);
-            im[brev(n1, ilog2(P))] = mul_zero_wins(xc[2 * n1 + 1], wv.y);
+            z1[brev(n1, ilog2(P))] = v2f{mul_zero_wins(xc[2 * n1], wv.x), mul_zero_wins(xc[2 * n1 + 1], wv.y)};
         }
         if (any) {
-        fft_regs<P>(re, im, twp);
+        fft_regs<P>(z1, twp);
         // ---- 2. twiddle W_H^(j k1) and 3. transpose through LDS: Y[k1][j]
 #pragma unroll
-        for (int k1 = 0; k1 < P; ++k1) {
-            const float2 w = s_tw2[k1 * 16 + j];
-            float2 v;
-            v.x = w.x * re[k1] - w.y * im[k1];
-            v.y = w.x * im[k1] + w.y * re[k1];
-            Y[k1 * 17 + j] = v;
-        }
+        for (int k1 = 0; k1 < P; ++k1) Y[k1 * 17 + j] = cmul(s_tw2[k1 * 16 + j], z1[k1]);
         wave_sync();
-        float zr[KB][16], zi[KB][16];
+        v2f z2[KB][16];
 #pragma unroll
         for (int i = 0; i < KB; ++i) {
             const int k1 = j + 16 * i;
 #pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) {
-                const float2 v = Y[k1 * 17 + n2];
-                zr[i][brev(n2, 4)] = v.x;
-                zi[i][brev(n2, 4)] = v.y;
-            }
+            for (int n2 = 0; n2 < 16; ++n2) z2[i][brev(n2, 4)] = Y[k1 * 17 + n2];
         }
         wave_sync();
 #pragma unroll
         for (int i = 0; i < KB; ++i) {
-            fft_regs<16>(zr[i], zi[i], tw16);
+            fft_regs<16>(z2[i], tw16);
             // Z[k1 + P k2] in natural order over the same LDS region
 #pragma unroll
-            for (int k2 = 0; k2 < 16; ++k2) Y[j + 16 * i + P * k2] = make_float2(zr[i][k2], zi[i][k2]);
+            for (int k2 = 0; k2 < 16; ++k2) Y[j + 16 * i + P * k2] = z2[i][k2];
         }
         wave_sync();
         // ---- 4. real-input spectrum, power / N.  Bins k and H-k share their inputs.
-        const float inv_n = 1.0f / (float)N;
-        float2 zks[P / 2], zcs[P / 2];
+        const float quarter_inv_n = 0.25f / (float)N;
+        v2f zks[P / 2], zcs[P / 2];
 #pragma unroll
         for (int mm = 0; mm < P / 2; ++mm) {
             const int k = j + 16 * mm;            // 0 .. H/2-1 ; partner H-k
             zks[mm] = Y[k];
             zcs[mm] = Y[(H - k) & (H - 1)];
         }
-        const float2 zh = Y[H / 2];
+        const v2f zh = Y[H / 2];
         wave_sync();                              // Z is in registers: pw may take its place
 #pragma unroll
         for (int mm = 0; mm < P / 2; ++mm) {
             const int k = j + 16 * mm;
-            const float2 zk = zks[mm], zc = zcs[mm];
-            const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
-            const float orr = 0.5f * (zk.y + zc.y), oi = -0.5f * (zk.x - zc.x);
-            const float2 w = s_tw[k];
-            // X[k] = E + W^k O ;  X[H-k] = conj(E - W^k O)
-            const float pr = w.x * orr - w.y * oi, pi_ = w.x * oi + w.y * orr;
-            const float xr = er + pr, xi = ei + pi_;
-            const float yr = er - pr, yi = ei - pi_;
-            pw[k] = (xr * xr + xi * xi) * inv_n;
-            pw[H - k] = (yr * yr + yi * yi) * inv_n;
+            // with E = (Z[k] + conj Z[H-k]) / 2 and O = -i (Z[k] - conj Z[H-k]) / 2:
+            // X[k] = E + W^k O ;  X[H-k] = conj(E - W^k O).  The halves are left out
+            // until the end (|2X|^2 / 4).
+            const v2f cc = {zcs[mm].x, -zcs[mm].y};
+            const v2f e2 = zks[mm] + cc, dd = zks[mm] - cc;
+            const v2f o2 = {dd.y, -dd.x};
+            const v2f pp = cmul(s_tw[k], o2);
+            const v2f xa = e2 + pp, xb = e2 - pp;
+            const v2f qa = xa * xa, qb = xb * xb;
+            pw[k] = (qa.x + qa.y) * quarter_inv_n;
+            pw[H - k] = (qb.x + qb.y) * quarter_inv_n;
         }
         if (j == 0) {   // k = H/2 is its own partner: E = (zr, 0), O = (zi, 0), W^(H/2) = -i
-            pw[H / 2] = (zh.x * zh.x + zh.y * zh.y) * inv_n;
+            pw[H / 2] = (zh.x * zh.x + zh.y * zh.y) * (4.f * quarter_inv_n);
         }
         if (j < 3) pw[H + 1 + j] = 0.f;           // padding that meets zero weights: keep it finite
         wave_sync();
@@ -438,11 +439,20 @@ int launch_fast(srx_context* h, const float* audio, const int64_t* so, int64_t U
 int srx_mfcc_fast_cepstra(srx_context* h, srx_mfcc_plan* p, const float* audio, const int64_t* so,
                           int64_t U, int64_t total, float* cep, hipStream_t st) {
     const srx_mfcc_cfg_t& c = p->cfg;
-    if (!p->mm_ok || (c.nfft != 512 && c.nfft != 1024) || total >= 0xFFFFFFFFll) return SRX_EUNSUPPORTED;
+    if (!p->mm_ok || (c.nfft != 512 && c.nfft != 1024) || total >= 0x7FFFFF00ll || c.hop < 2)
+        return SRX_EUNSUPPORTED;
     FastDev d;
     d.frame_len = c.frame_len; d.hop = c.hop;
     d.n_used = c.frame_len < c.nfft ? c.frame_len : c.nfft;
     d.n_mel = c.n_mel; d.n_ceps = c.n_ceps; d.nnz = p->nnz;
+    {
+        // l = ceil(log2 hop), m = ceil(2^(31+l) / hop) < 2^32: floor(n / hop) = (n m) >> (31 + l)
+        int l = 0;
+        while ((1ll << l) < c.hop) ++l;
+        const unsigned __int128 one = 1;
+        d.hop_m = (unsigned)(((one << (31 + l)) + c.hop - 1) / (unsigned)c.hop);
+        d.hop_s = (unsigned)(l - 1);
+    }
     d.nq = p->mm_nq; d.kk = p->mm_kk; d.groups = p->mm_groups;
     d.mm_w = (const float*)p->mm_w; d.mm_dct = (const float*)p->mm_dct; d.mm_meta = p->mm_meta;
     d.log_mult = (float)c.log_mult;
