@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -322,108 +323,8 @@ __global__ __launch_bounds__(256) void finish_stream_kernel(
         const T* cu = cep + (s0 / c.hop) * K;
         T* ou = out + fo[u] * NF;
         const int64_t n_tiles = (To + tile_rows - 1) / tile_rows;
-        if (threadIdx.x < NF) {
-            col_mean[threadIdx.x] = (T)0;
-            col_scale[threadIdx.x] = (T)1;
-        }
-        const int first = zscore ? 0 : 2;
-        for (int phase = first; phase < 3; ++phase) {
-            double acc[3] = {0.0, 0.0, 0.0};
-            T mean[3], inv[3];
-            __syncthreads();                    // col_mean / col_scale of the previous phase
-#pragma unroll
-            for (int o = 0; o < 3; ++o) {
-                mean[o] = o <= order ? col_mean[o * K + k] : (T)0;
-                inv[o] = o <= order ? (T)1 / col_scale[o * K + k] : (T)1;
-            }
-            for (int64_t ti = 0; ti < n_tiles; ++ti) {
-                const int64_t t0 = trim + ti * tile_rows;
-                const int64_t t1 = t0 + tile_rows < Tu - trim ? t0 + tile_rows : Tu - trim;
-                const int64_t lo = t0 - 2 * N > 0 ? t0 - 2 * N : 0;
-                const int64_t hi = t1 + 2 * N < Tu ? t1 + 2 * N : Tu;
-                if (n_tiles > 1 || phase == first) {
-                    __syncthreads();            // walkers of the previous tile
-                    const int cnt = (int)(hi - lo) * K;
-                    const T* src = cu + lo * K;
-                    // (8 loads in flight per thread: one at a time, the copy would take
-                    // a memory round trip per 256 elements)
-                    for (int i0 = threadIdx.x; i0 < cnt; i0 += 8 * blockDim.x) {
-                        T v[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const int i = i0 + q * blockDim.x;
-                            v[q] = i < cnt ? src[i] : (T)0;
-                        }
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const int i = i0 + q * blockDim.x;
-                            if (i < cnt) tile[i] = v[q];
-                        }
-                    }
-                    __syncthreads();
-                }
-                if (seg >= nseg) continue;
-                const int64_t per = (t1 - t0 + nseg - 1) / nseg;
-                const int64_t a = t0 + seg * per;
-                const int64_t b = a + per < t1 ? a + per : t1;
-                if (a >= b) continue;
-                // (32-bit row numbers relative to the tile: a clamp is one instruction)
-                const T* col = tile + k;
-                const int r_lo = (int)(0 - lo), r_hi = (int)(Tu - 1 - lo);   // rows 0 and Tu-1
-                auto d1 = [&](int s) {
-                    s = min(max(s, r_lo), r_hi);
-                    T v = 0;
-#pragma unroll
-                    for (int j = -N; j <= N; ++j) {
-                        if (j == 0) continue;
-                        const int tt = min(max(s + j, r_lo), r_hi);
-                        v += (T)j * col[tt * K];
-                    }
-                    return v * inv_den;
-                };
-                const int ra = (int)(a - lo), rb = (int)(b - lo);
-                T* orow = ou + (a - trim) * NF + k;
-                T w[2 * N + 1];
-#pragma unroll
-                for (int i = 0; i <= 2 * N; ++i) w[i] = (T)0;
-                if (order >= 2) {
-#pragma unroll
-                    for (int i = 0; i < 2 * N; ++i) w[i + 1] = d1(ra - N + i);
-                } else if (order == 1) {
-                    w[N + 1] = d1(ra);          // (becomes the centre after the first shift)
-                }
-                for (int t = ra; t < rb; ++t) {
-                    T v[3];
-                    v[0] = col[t * K];
-#pragma unroll
-                    for (int i = 0; i < 2 * N; ++i) w[i] = w[i + 1];
-                    if (order >= 2) {
-                        w[2 * N] = d1(t + N);
-                        T a2 = 0;
-#pragma unroll
-                        for (int i = -N; i <= N; ++i) a2 += (T)i * w[N + i];
-                        v[2] = a2 * inv_den;
-                    } else {
-                        v[2] = (T)0;
-                        if (order == 1) w[N + 1] = d1(t + 1);
-                    }
-                    v[1] = w[N];
-#pragma unroll
-                    for (int o = 0; o < 3; ++o) {
-                        if (o > order) continue;
-                        if (phase == 0) {
-                            acc[o] += (double)v[o];
-                        } else if (phase == 1) {
-                            const double d = (double)v[o] - (double)mean[o];
-                            acc[o] += d * d;
-                        } else {
-                            orow[o * K] = (v[o] - mean[o]) * inv[o];
-                        }
-                    }
-                    orow += NF;
-                }
-            }
-            if (phase == 2) break;
+        // column sums of a phase -> col_mean (phase 0) or col_scale (phase 1)
+        auto reduce = [&](int phase, const double (&acc)[3]) {
 #pragma unroll
             for (int o = 0; o < 3; ++o) red[o * 256 + threadIdx.x] = seg < nseg ? acc[o] : 0.0;
             __syncthreads();
@@ -443,6 +344,190 @@ __global__ __launch_bounds__(256) void finish_stream_kernel(
                     col_scale[threadIdx.x] = sc;
                 }
             }
+            __syncthreads();
+        };
+        // rows [lo, hi) of the utterance's cepstra -> tile
+        auto load_tile = [&](int64_t lo, int64_t hi) {
+            __syncthreads();                    // walkers of the previous tile
+            const int cnt = (int)(hi - lo) * K;
+            const T* src = cu + lo * K;
+            // (8 loads in flight per thread: one at a time, the copy would take a
+            // memory round trip per 256 elements)
+            for (int i0 = threadIdx.x; i0 < cnt; i0 += 8 * blockDim.x) {
+                T v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = i0 + q * blockDim.x;
+                    v[q] = i < cnt ? src[i] : (T)0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = i0 + q * blockDim.x;
+                    if (i < cnt) tile[i] = v[q];
+                }
+            }
+            __syncthreads();
+        };
+        // One walk of rows [a, b) (utterance rows; the tile starts at row lo): emit(q, t, v)
+        // gets the q-th row's c, delta, delta-delta.  UNROLL > 0 unrolls the walk that many
+        // times under a row-count predicate, so that emit may index registers by q.
+        auto walk = [&](auto unroll, int64_t lo, int64_t a, int64_t b, auto&& emit) {
+            constexpr int UN = decltype(unroll)::value;
+            // (32-bit row numbers relative to the tile: a clamp is one instruction)
+            const T* col = tile + k;
+            const int r_lo = (int)(0 - lo), r_hi = (int)(Tu - 1 - lo);   // rows 0 and Tu-1
+            auto d1 = [&](int s) {
+                s = min(max(s, r_lo), r_hi);
+                T v = 0;
+#pragma unroll
+                for (int j = -N; j <= N; ++j) {
+                    if (j == 0) continue;
+                    const int tt = min(max(s + j, r_lo), r_hi);
+                    v += (T)j * col[tt * K];
+                }
+                return v * inv_den;
+            };
+            const int ra = (int)(a - lo), rb = (int)(b - lo);
+            T w[2 * N + 1];
+#pragma unroll
+            for (int i = 0; i <= 2 * N; ++i) w[i] = (T)0;
+            if (order >= 2) {
+#pragma unroll
+                for (int i = 0; i < 2 * N; ++i) w[i + 1] = d1(ra - N + i);
+            } else if (order == 1) {
+                w[N + 1] = d1(ra);              // (becomes the centre after the first shift)
+            }
+            auto row = [&](int q, int t) {
+                T v[3];
+                v[0] = col[t * K];
+#pragma unroll
+                for (int i = 0; i < 2 * N; ++i) w[i] = w[i + 1];
+                if (order >= 2) {
+                    w[2 * N] = d1(t + N);
+                    T a2 = 0;
+#pragma unroll
+                    for (int i = -N; i <= N; ++i) a2 += (T)i * w[N + i];
+                    v[2] = a2 * inv_den;
+                } else {
+                    v[2] = (T)0;
+                    if (order == 1) w[N + 1] = d1(t + 1);
+                }
+                v[1] = w[N];
+                emit(q, t, v);
+            };
+            if constexpr (UN > 0) {
+#pragma unroll
+                for (int q = 0; q < UN; ++q)
+                    if (ra + q < rb) row(q, ra + q);
+            } else {
+                for (int t = ra; t < rb; ++t) row(0, t);
+            }
+        };
+        const int first = zscore ? 0 : 2;
+        // ---- short utterances, float32: one walk, the rows stay in registers
+        constexpr int RMAX = 16;
+        if constexpr (sizeof(T) == 4) {
+            const int64_t per = (To + nseg - 1) / nseg;
+            if (n_tiles == 1 && per <= RMAX) {
+                const int64_t lo = 0, hi = Tu;
+                load_tile(lo, hi);
+                const int64_t a = trim + seg * per;
+                const int64_t b = a + per < Tu - trim ? a + per : Tu - trim;
+                const bool mine = seg < nseg && a < b;
+                T r[RMAX][3];
+#pragma unroll
+                for (int q = 0; q < RMAX; ++q) r[q][0] = r[q][1] = r[q][2] = (T)0;
+                if (mine)
+                    walk(std::integral_constant<int, RMAX>{}, lo, a, b, [&](int q, int, const T (&v)[3]) {
+                        r[q][0] = v[0];
+                        r[q][1] = v[1];
+                        r[q][2] = v[2];
+                    });
+                const int nrow = mine ? (int)(b - a) : 0;
+                T mean[3] = {(T)0, (T)0, (T)0}, inv[3] = {(T)1, (T)1, (T)1};
+                if (zscore) {
+                    double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < RMAX; ++q)
+                        if (q < nrow) {
+#pragma unroll
+                            for (int o = 0; o < 3; ++o) acc[o] += (double)r[q][o];
+                        }
+                    __syncthreads();            // (red / col_* of the previous utterance)
+                    reduce(0, acc);
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) {
+                        mean[o] = o <= order ? col_mean[o * K + k] : (T)0;
+                        acc[o] = 0.0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < RMAX; ++q)
+                        if (q < nrow) {
+#pragma unroll
+                            for (int o = 0; o < 3; ++o) {
+                                const double d = (double)r[q][o] - (double)mean[o];
+                                acc[o] += d * d;
+                            }
+                        }
+                    reduce(1, acc);
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) inv[o] = o <= order ? (T)1 / col_scale[o * K + k] : (T)1;
+                }
+                T* orow = ou + (a - trim) * NF + k;
+#pragma unroll
+                for (int q = 0; q < RMAX; ++q)
+                    if (q < nrow) {
+#pragma unroll
+                        for (int o = 0; o < 3; ++o)
+                            if (o <= order) orow[(int64_t)q * NF + o * K] = (r[q][o] - mean[o]) * inv[o];
+                    }
+                continue;
+            }
+        }
+        // ---- any length: a walk per phase
+        if (threadIdx.x < NF) {
+            col_mean[threadIdx.x] = (T)0;
+            col_scale[threadIdx.x] = (T)1;
+        }
+        for (int phase = first; phase < 3; ++phase) {
+            double acc[3] = {0.0, 0.0, 0.0};
+            T mean[3], inv[3];
+            __syncthreads();                    // col_mean / col_scale of the previous phase
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                mean[o] = o <= order ? col_mean[o * K + k] : (T)0;
+                inv[o] = o <= order ? (T)1 / col_scale[o * K + k] : (T)1;
+            }
+            for (int64_t ti = 0; ti < n_tiles; ++ti) {
+                const int64_t t0 = trim + ti * tile_rows;
+                const int64_t t1 = t0 + tile_rows < Tu - trim ? t0 + tile_rows : Tu - trim;
+                const int64_t lo = t0 - 2 * N > 0 ? t0 - 2 * N : 0;
+                const int64_t hi = t1 + 2 * N < Tu ? t1 + 2 * N : Tu;
+                if (n_tiles > 1 || phase == first) load_tile(lo, hi);
+                if (seg >= nseg) continue;
+                const int64_t per = (t1 - t0 + nseg - 1) / nseg;
+                const int64_t a = t0 + seg * per;
+                const int64_t b = a + per < t1 ? a + per : t1;
+                if (a >= b) continue;
+                T* orow = ou + (a - trim) * NF + k;
+                walk(std::integral_constant<int, 0>{}, lo, a, b, [&](int, int, const T (&v)[3]) {
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) {
+                        if (o > order) continue;
+                        if (phase == 0) {
+                            acc[o] += (double)v[o];
+                        } else if (phase == 1) {
+                            const double d = (double)v[o] - (double)mean[o];
+                            acc[o] += d * d;
+                        } else {
+                            orow[o * K] = (v[o] - mean[o]) * inv[o];
+                        }
+                    }
+                    orow += NF;
+                });
+            }
+            if (phase == 2) break;
+            reduce(phase, acc);
         }
         __syncthreads();
     }

@@ -248,6 +248,36 @@ def test_mfcc_batch_ragged_equals_single(sra, ctx, mfcc_golden):
                                        atol=1e-4 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("seconds,delta_order,zscore", [(3.5, 2, True), (9.0, 2, True), (9.0, 1, True),
+                                                        (9.0, 0, True), (5.0, 2, False), (0.5, 1, False)])
+def test_mfcc_long_utterances(sra, ctx, seconds, delta_order, zscore):
+    """Utterances longer than what one thread keeps in registers (more than 16 rows per
+    row segment) and longer than one staging tile of the delta / z-score stage, mixed
+    with short ones in one batch, against the oracle (float64 1e-7 absolute on z-scored,
+    float32 1e-4 of the largest value un-normalised, 3e-3 absolute z-scored)."""
+    rng = np.random.default_rng(int(seconds * 10) + delta_order)
+    n = int(seconds * 16000)
+    t = np.arange(n) / 16000.0
+    long_sig = 0.1 * rng.standard_normal(n) + 0.2 * np.sin(2 * np.pi * (300 + 40 * t) * t)
+    sigs = [0.1 * rng.standard_normal(4000), long_sig, 0.1 * rng.standard_normal(16000)]
+    cfg = mo.MfccConfig(sample_rate=16000, nfft=512, n_mel=40, delta_order=delta_order, zscore=zscore)
+    refs = [mo.extract(s.astype(np.float64), cfg) for s in sigs]
+    for dtype in ("float64", "float32"):
+        f, lens = sra.mfcc.extract_batch([s.astype(np.float32) if dtype == "float32" else s for s in sigs],
+                                         16000, nfft=512, n_mel=40, delta_order=delta_order,
+                                         zscore=zscore, dtype=dtype)
+        off = np.concatenate([[0], np.cumsum(lens)])
+        for k, ref in enumerate(refs):
+            got = f[off[k]:off[k + 1]]
+            assert got.shape == ref.shape
+            if dtype == "float64":
+                np.testing.assert_allclose(got, ref, rtol=0, atol=1e-7 * max(1.0, np.abs(ref).max()))
+            elif zscore:
+                np.testing.assert_allclose(got, ref, rtol=0, atol=3e-3)
+            else:
+                np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
 def test_class_surface_and_errors(sra, ctx, hmm_golden):
     g, p = hmm_golden, "s3d26_"
     m = sra.MyGaussianHMM(n_components=3, tol=1e-4, n_iter=2, implementation="scaling",
