@@ -190,7 +190,19 @@ def main():
                             "hbm_frac": n_fr * (N_FEAT * 4 + 4) / dtv / 1e9 / HBM_PEAK_GBS,
                             "config": "one 8-state model per utterance (u mod 6), int32 path out "
                                       "(156 B in + 4 B out per frame)"}
-        del vlp, vpath, um
+        del vlp, vpath
+        plp, pgam = bank.posteriors(data, um)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            plp, pgam = bank.posteriors(data, um)
+        barrier()
+        dtp = (time.perf_counter() - t0) / 3
+        extra["posteriors"] = {"frames_per_s": n_fr * world / dtp, "ms": dtp * 1e3,
+                               "hbm_frac": n_fr * (N_FEAT + N_STATES) * 4 / dtp / 1e9 / HBM_PEAK_GBS,
+                               "config": "state posteriors, one 8-state model per utterance (u mod 6), "
+                                         "float32 (156 B in + 32 B out per frame)"}
+        del plp, pgam, um
         del X, data
         torch.cuda.empty_cache()
         # front-end: 16 kHz, 25/10 ms, 512-pt FFT, 40 mel, 13 ceps + delta + delta-delta

@@ -623,8 +623,15 @@ int posteriors_t(srx_context* h, const void* X, const int64_t* off, int64_t U, i
     if (rc) return rc;
     // (plain float32 emission: the split-bfloat16 matrix-core emission is good to
     // 1e-4 in the log-density, which shows in small posteriors)
-    hipLaunchKernelGGL(emission_kernel<T>, dim3(grid_for(h, U, 1)), dim3(kBlock), 0, st,
-                       (const T*)X, off, U, utt_model, 0, M, S, D, tb, ll);
+    bool done = false;
+    if constexpr (std::is_same<T, float>::value) {
+        rc = srx_mfma_emission_utt_f32(h, X, off, U, n_frames, utt_model, md, (float*)ll, st);
+        if (rc == SRX_OK) done = true;
+        else if (rc != SRX_EUNSUPPORTED) return rc;
+    }
+    if (!done)
+        hipLaunchKernelGGL(emission_kernel<T>, dim3(grid_for(h, U, 1)), dim3(kBlock), 0, st,
+                           (const T*)X, off, U, utt_model, 0, M, S, D, tb, ll);
     const int sp = sub_width(S);
     SP_DISPATCH(sp, hipLaunchKernelGGL((fb_chain_kernel<T, SP>),
                                        dim3(grid_for(h, U, kBlock / SP)), dim3(kBlock), 0, st,

@@ -398,6 +398,121 @@ __global__ __launch_bounds__(256) void emission_utt_split_kernel(
     }
 }
 
+// The same output with the contraction in plain float32 on v_mfma_f32_16x16x4_f32
+// (posteriors need the log-densities to float32 rounding, not to the 1e-4 of the
+// split-bf16 product).  Weight table per model: one 16-row tile,
+// W[row][q][x | x^2][g][i] = coefficient of feature 16 q + 4 g + i, natural-log units;
+// lane (g, ul) keeps row ul's coefficients for its own k slots in registers.
+__global__ void emission_f32_prep_kernel(srx_models_t md, int RQ, float* W, float* cst) {
+    const int M = md.n_models, S = md.n_states, D = md.n_features;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    const int per_row = RQ * 32;
+    for (int i = tid; i < M * 16 * per_row; i += nth) {
+        const int row = i / per_row, w = i % per_row;
+        const int q = w >> 5, e = (w >> 4) & 1, d = 16 * q + (w & 15);
+        const int m = row >> 4, s_ = row & 15;
+        float v = 0.f;
+        if (s_ < S && d < D) {
+            const size_t k = ((size_t)m * S + s_) * D + d;
+            const double var = fmax(md.covars[k], 2.2250738585072014e-308);
+            v = (float)(e ? -0.5 / var : md.means[k] / var);
+        }
+        W[i] = v;
+    }
+    for (int row = tid; row < M * 16; row += nth) {
+        const int m = row >> 4, s_ = row & 15;
+        float v = 0.f;
+        if (s_ < S) {
+            double acc = D * 1.8378770664093453;
+            for (int d = 0; d < D; ++d) {
+                const size_t k = ((size_t)m * S + s_) * D + d;
+                const double var = fmax(md.covars[k], 2.2250738585072014e-308);
+                acc += log(var) + md.means[k] * md.means[k] / var;
+            }
+            v = (float)(-0.5 * acc);
+        }
+        cst[row] = v;
+    }
+}
+
+template <int RQ>
+__global__ __launch_bounds__(256) void emission_utt_f32_kernel(
+    const float* __restrict__ X, const int64_t* __restrict__ off, int64_t U, int64_t n_frames,
+    const int32_t* __restrict__ utt_model, int S, int D, const float* __restrict__ W,
+    const float* __restrict__ cst, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, ul = lane & 15;
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const unsigned lane_off = (unsigned)ul * (unsigned)D * 4u + 16u * g;
+    int cur = -1;
+    f32x4 w1[RQ], w2[RQ];
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) w1[q] = w2[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t u = wid; u < U; u += n_waves) {
+        const int m = utt_model ? utt_model[u] : 0;
+        const int64_t f0 = off[u];
+        const int64_t T = off[u + 1] - f0;
+        if (T <= 0) continue;
+        if (m != cur) {
+            cur = m;
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const float* p = W + (((size_t)(m * 16 + ul)) * RQ + q) * 32 + 4 * g;
+                w1[q] = *(const f32x4*)p;
+                w2[q] = *(const f32x4*)(p + 16);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c0[r] = cst[m * 16 + 4 * g + r];
+        }
+        const int64_t n_groups = (T + 15) / 16;
+        auto load = [&](int64_t k, u32x4 (&dst)[RQ]) {
+            // descriptor over [first frame of the group, end of the utterance)
+            const int64_t fk = k < n_groups ? f0 + k * 16 : f0;
+            const int64_t rest = k < n_groups ? (f0 + T - fk) * (int64_t)D * 4 : 0;
+            const uintptr_t a = (uintptr_t)(X + fk * D);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+            const unsigned n = (unsigned)(rest < 0xFFFFFF00ll ? rest : 0xFFFFFF00ll);
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
+#pragma unroll
+            for (int q = 0; q < RQ; ++q)
+                dst[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off + 64u * q, 0, 0);
+        };
+        u32x4 xa[RQ], xb[RQ];
+        load(0, xa);
+        for (int64_t k = 0; k < n_groups; ++k) {
+            load(k + 1, xb);
+            f32x4 a1 = c0, a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const f32x4 x = __builtin_bit_cast(f32x4, xa[q]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[q][i], x[i], a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[q][i], x[i] * x[i], a2, 0, 0, 0);
+                }
+            }
+            const int64_t t = k * 16 + ul;
+            if (t < T) {
+                float* o = out + (f0 + t) * S;
+                const int col = 4 * g;
+                const f32x4 v = a1 + a2;
+                if ((S & 3) == 0 && col + 3 < S) {
+                    *(f32x4*)(o + col) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col + r < S) o[col + r] = v[r];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) xa[q] = xb[q];
+        }
+    }
+}
+
 template <int SP, int NT, int R>
 void launch(const float* X, const int64_t* off, int64_t U, int64_t n_frames, int M, int S, int D,
             MfmaTables tb, double* out, hipStream_t st) {
@@ -476,6 +591,34 @@ int srx_mfma_emission_utt(srx_context* h, const void* X, const int64_t* off, int
                            st, Xf, off, U, n_frames, utt_model, S, D, tb, out);               \
         SRX_HIP(hipGetLastError());                                                           \
         return SRX_OK;                                                                        \
+    }
+    SRX_CASE(3) SRX_CASE(2) SRX_CASE(1)
+#undef SRX_CASE
+    return SRX_EUNSUPPORTED;
+}
+
+int srx_mfma_emission_utt_f32(srx_context* h, const void* X, const int64_t* off, int64_t U,
+                              int64_t n_frames, const int32_t* utt_model, const srx_models_t* md,
+                              float* out, hipStream_t st) {
+    const int M = md->n_models, S = md->n_states, D = md->n_features;
+    if (S > 16 || D > 48 || M > 4096 || n_frames <= 0 || U <= 0) return SRX_EUNSUPPORTED;
+    const int RQ = (D + 15) / 16;
+    const size_t n_w = (size_t)M * 16 * RQ * 32, n_c = (size_t)M * 16;
+    float* base;
+    int rc = srx_ws_ensure(h, WS_MISC, 4 * (n_w + n_c), (void**)&base);
+    if (rc) return rc;
+    float* cst = base + n_w;
+    hipLaunchKernelGGL(emission_f32_prep_kernel, dim3(16), dim3(256), 0, st, *md, RQ, base, cst);
+    int64_t gx = (U + 3) / 4;
+    const int64_t cap = (int64_t)h->n_cu * 8;
+    if (gx > cap) gx = cap;
+    const float* Xf = (const float*)X;
+#define SRX_CASE(rq)                                                                        \
+    if (RQ == rq) {                                                                         \
+        hipLaunchKernelGGL((emission_utt_f32_kernel<rq>), dim3((unsigned)gx), dim3(256), 0, \
+                           st, Xf, off, U, n_frames, utt_model, S, D, base, cst, out);      \
+        SRX_HIP(hipGetLastError());                                                         \
+        return SRX_OK;                                                                      \
     }
     SRX_CASE(3) SRX_CASE(2) SRX_CASE(1)
 #undef SRX_CASE

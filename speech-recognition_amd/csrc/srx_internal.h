@@ -118,6 +118,10 @@ int srx_mfma_emission(srx_context* h, const void* X, int64_t n_frames, const srx
 int srx_mfma_emission_utt(srx_context* h, const void* X, const int64_t* off, int64_t U,
                           int64_t n_frames, const int32_t* utt_model, const srx_models_t* md,
                           float* out, hipStream_t st);
+// Same output, plain float32 products (no split-bf16).
+int srx_mfma_emission_utt_f32(srx_context* h, const void* X, const int64_t* off, int64_t U,
+                          int64_t n_frames, const int32_t* utt_model, const srx_models_t* md,
+                          float* out, hipStream_t st);
 int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
                    int64_t n_frames, const srx_models_t* models, double* out,
                    hipStream_t st);
