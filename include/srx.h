@@ -128,6 +128,32 @@ int srx_mfcc_batch(srx_handle_t h, srx_mfcc_plan_t plan, const void* audio, int 
  * HOST memory: mel_filterbank, mfcc.py:47-61 (diagnostic, no GPU needed). */
 int srx_mfcc_filterbank_host(const srx_mfcc_cfg_t* cfg, double* out_dense);
 
+/* ---- end-pointing in front of the front-end: AudioMonitor.start_saved_audio with
+ * compute_short_time_energy, compute_zero_crossing_rate_sum, detect_if_noise,
+ * detect_speech_start_2, calc_N1_prime, calc_N2_prime
+ * (new_speech_detect.py:44-61, :80-89, :197-334), for many recordings per call. */
+typedef struct {
+    int32_t sample_rate;     /* Hz */
+    int32_t block_ms;        /* block length, reference: 10 */
+    int32_t zcr_cap;         /* upper bound of the zero-crossing threshold, reference: 25 */
+    int32_t reserved;
+    double noise_peak;       /* a recording whose peak block energy is below is noise, reference: 4.5 */
+} srx_endpoint_cfg_t;
+/* Blocks of a recording of n_samples: ceil(n_samples / int(sample_rate * block_ms / 1000)). */
+int64_t srx_endpoint_blocks(const srx_endpoint_cfg_t* cfg, int64_t n_samples);
+/* audio: packed samples (dtype), sample_offsets[R+1]; block_offsets[R+1]: cumulative
+ * srx_endpoint_blocks of every recording (device, int64), n_blocks their total.
+ * out_energy[n_blocks] (double) = sum |x| per block, out_zcr[n_blocks] = sign changes
+ * inside the block.  Per recording: out_counts[r] segments found (may exceed
+ * max_segments; the first max_segments are stored), out_segments[r][k] =
+ * {N1', N1, N2, N2'} in blocks, out_thresholds[r] = {ITU, ITL, IZCT}, or
+ * {peak energy, 0, 0} when nothing is found. */
+int srx_endpoint_detect(srx_handle_t h, const void* audio, int dtype, const int64_t* sample_offsets,
+                        int64_t n_recordings, int64_t n_samples, const srx_endpoint_cfg_t* cfg,
+                        const int64_t* block_offsets, int64_t n_blocks, double* out_energy,
+                        int32_t* out_zcr, int32_t* out_segments, int32_t* out_counts,
+                        double* out_thresholds, int32_t max_segments, void* stream);
+
 /* ---- emissions: _log_multivariate_normal_density_diag, hmm.py:154-163 ----
  * out[f, m*S + s] for every frame and every state of every model (dtype). */
 int srx_emission_loglik(srx_handle_t h, const void* X, int dtype, int64_t n_frames,

@@ -48,6 +48,11 @@ class MfccCfg(C.Structure):
                 ("zscore", C.c_int32), ("log_mult", C.c_double)]
 
 
+class EndpointCfg(C.Structure):
+    _fields_ = [("sample_rate", C.c_int32), ("block_ms", C.c_int32), ("zcr_cap", C.c_int32),
+                ("reserved", C.c_int32), ("noise_peak", C.c_double)]
+
+
 _vp, _i64, _i32 = C.c_void_p, C.c_int64, C.c_int32
 
 # name -> (restype, argtypes); must list every symbol include/srx.h declares.
@@ -64,6 +69,9 @@ SIGNATURES = {
     "srx_mfcc_out_frames": (_i64, [C.POINTER(MfccCfg), _i64]),
     "srx_mfcc_batch": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _i64, _i64, _vp, _vp, _vp]),
     "srx_mfcc_filterbank_host": (C.c_int, [C.POINTER(MfccCfg), _vp]),
+    "srx_endpoint_blocks": (_i64, [C.POINTER(EndpointCfg), _i64]),
+    "srx_endpoint_detect": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, C.POINTER(EndpointCfg), _vp,
+                                      _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "srx_emission_loglik": (C.c_int, [_vp, _vp, C.c_int, _i64, C.POINTER(Models), _vp, _vp]),
     "srx_forward_score": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, C.POINTER(Models), _vp, _vp]),
     "srx_forward_score_generic": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, C.POINTER(Models), _vp, _vp]),

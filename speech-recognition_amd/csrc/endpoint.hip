@@ -1,0 +1,221 @@
+// End-pointing in front of the MFCC path: the energy / zero-crossing block features
+// and the run search of the reference's AudioMonitor (new_speech_detect.py:30-61,
+// :80-89, :197-343), for many recordings at once.
+//
+//   endpoint_blocks_kernel   16 lanes per 10 ms block: sum of |x| (float64) and the
+//                            number of sign changes inside the block.  One pass over
+//                            the samples: 4 (or 8) bytes read per sample, 12 bytes
+//                            written per block.
+//   endpoint_detect_kernel   one thread per recording: peak / floor energies, the
+//                            three thresholds, the sequential run search over the
+//                            recording's blocks, widening by the zero-crossing rule.
+#include "srx_internal.h"
+
+#include <math.h>
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void endpoint_blocks_kernel(
+    const T* __restrict__ audio, const int64_t* __restrict__ so, const int64_t* __restrict__ bo,
+    int64_t n_rec, int64_t n_blocks, int block, double* __restrict__ energy,
+    int32_t* __restrict__ zcr) {
+    const int j = threadIdx.x & 15;
+    const int64_t sub = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t nsub = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    // the recording under a block advances monotonically with the block index
+    int64_t rec = 0;
+    for (int64_t b = sub; b < n_blocks; b += nsub) {
+        // recording of block b: last rec with bo[rec] <= b (binary search from the
+        // previous position)
+        if (!(bo[rec] <= b && b < bo[rec + 1])) {
+            int64_t lo = rec, hi = n_rec;
+            if (bo[rec] > b) lo = 0;
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (bo[mid] <= b) lo = mid; else hi = mid;
+            }
+            rec = lo;
+        }
+        const int64_t s_begin = so[rec] + (b - bo[rec]) * block;
+        const int64_t s_end = so[rec + 1];
+        const int len = (int)(s_end - s_begin < block ? s_end - s_begin : block);
+        const T* x = audio + s_begin;
+        double e = 0.0;
+        int z = 0;
+        for (int i = j; i < len; i += 16) {
+            const T v = x[i];
+            e += (double)fabs(v);
+            if (i + 1 < len) z += (v >= (T)0) != (x[i + 1] >= (T)0);
+        }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) {
+            e += __shfl_xor(e, o, 16);
+            z += __shfl_xor(z, o, 16);
+        }
+        if (j == 0) {
+            energy[b] = e;
+            zcr[b] = z;
+        }
+    }
+}
+
+__global__ void endpoint_detect_kernel(const double* __restrict__ energy,
+                                       const int32_t* __restrict__ zcr,
+                                       const int64_t* __restrict__ bo, int64_t n_rec,
+                                       srx_endpoint_cfg_t c, int block, int max_seg,
+                                       int32_t* __restrict__ segs, int32_t* __restrict__ counts,
+                                       double* __restrict__ thr) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rec) return;
+    const int64_t b0 = bo[r];
+    const int n = (int)(bo[r + 1] - b0);
+    const double* e = energy + b0;
+    const int32_t* z = zcr + b0;
+    int32_t* out = segs + r * (int64_t)max_seg * 4;
+    double* t = thr + r * 3;
+    counts[r] = 0;
+    t[0] = t[1] = t[2] = 0.0;
+    if (n <= 0) return;
+    double imx = e[0], imn = e[0];
+    for (int i = 1; i < n; ++i) {
+        imx = fmax(imx, e[i]);
+        imn = fmin(imn, e[i]);
+    }
+    t[0] = imx;                                  // (reported when nothing is found)
+    if (imx < c.noise_peak) return;
+    const double itl = fmin(0.03 * (imx - imn) + imn, 4.0 * imn);
+    const double itu = 5.0 * itl;
+    // zero-crossing threshold from the blocks that begin in the first 100 ms (blocks
+    // past the end of a short recording count as zero)
+    const int first = (int)(0.1 * (double)c.sample_rate);
+    const int n0 = (first + block - 1) / block;
+    double mean = 0.0;
+    for (int i = 0; i < n0; ++i) mean += i < n ? (double)z[i] : 0.0;
+    mean = n0 > 0 ? mean / n0 : 0.0;
+    double var = 0.0;
+    for (int i = 0; i < n0; ++i) {
+        const double d = (i < n ? (double)z[i] : 0.0) - mean;
+        var += d * d;
+    }
+    var = n0 > 0 ? var / n0 : 0.0;
+    const double izct = fmin((double)c.zcr_cap, mean + 2.0 * sqrt(var));
+    // run search: `up` counts accepted runs above ITU, `cnt` accepted runs above ITL
+    int up = 0, up_last = 0, cnt = 0;
+    int u0 = -1, uc = 0, l0 = -1, ld = 0;
+    auto accept = [&](int n1, int d) {
+        const int n2 = n1 + d;
+        int hits = 0, first_hit = n1, last_hit = n2;
+        for (int i = n1 - 25 > 0 ? n1 - 25 : 0; i <= n1; ++i)
+            if ((double)z[i] > izct) {
+                if (hits == 0) first_hit = i;
+                ++hits;
+            }
+        const int n1p = hits >= 3 ? first_hit : n1;
+        hits = 0;
+        for (int i = n2 + 1; i < (n2 + 25 < n ? n2 + 25 : n); ++i)
+            if ((double)z[i] > izct) {
+                last_hit = i;
+                ++hits;
+            }
+        const int n2p = hits >= 3 ? last_hit : n2;
+        if (cnt < max_seg) {
+            out[4 * cnt + 0] = n1p - 10 > 0 ? n1p - 10 : 0;
+            out[4 * cnt + 1] = n1;
+            out[4 * cnt + 2] = n2;
+            out[4 * cnt + 3] = n2p;
+        }
+        ++cnt;
+    };
+    for (int i = 0; i < n; ++i) {
+        const double v = e[i];
+        if (v > itu) {
+            if (u0 == -1) u0 = i;
+            ++uc;
+            if (i == n - 1) {
+                ++up;
+                up_last = u0;
+                u0 = -1;
+                uc = 0;
+            }
+        } else {
+            if (uc > 5 || u0 == 0) {
+                ++up;
+                up_last = u0;
+            }
+            u0 = -1;
+            uc = 0;
+        }
+        if (v > itl) {
+            if (l0 == -1) l0 = i;
+            ++ld;
+            if (i == n - 1 && up > cnt && l0 <= up_last) {
+                accept(l0, ld);
+                l0 = -1;
+                ld = 0;
+            }
+        } else {
+            if (ld > 5 && up > cnt && l0 <= up_last) accept(l0, ld);
+            l0 = -1;
+            ld = 0;
+        }
+    }
+    counts[r] = cnt;
+    if (cnt > 0) {
+        t[0] = itu;
+        t[1] = itl;
+        t[2] = izct;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t srx_endpoint_blocks(const srx_endpoint_cfg_t* c, int64_t n_samples) {
+    if (!c || n_samples <= 0) return 0;
+    const int64_t block = (int64_t)((double)c->sample_rate * c->block_ms / 1000.0);
+    if (block < 1) return 0;
+    return (n_samples + block - 1) / block;
+}
+
+int srx_endpoint_detect(srx_handle_t h, const void* audio, int dtype, const int64_t* sample_offsets,
+                        int64_t n_recordings, int64_t n_samples, const srx_endpoint_cfg_t* cfg,
+                        const int64_t* block_offsets, int64_t n_blocks, double* out_energy,
+                        int32_t* out_zcr, int32_t* out_segments, int32_t* out_counts,
+                        double* out_thresholds, int32_t max_segments, void* stream) {
+    SRX_REQUIRE(h != nullptr && cfg != nullptr, "srx_endpoint_detect: NULL context or cfg");
+    SRX_REQUIRE(dtype == SRX_F32 || dtype == SRX_F64, "srx_endpoint_detect: unknown dtype %d", dtype);
+    SRX_REQUIRE(n_recordings >= 0 && n_samples >= 0 && n_blocks >= 0, "srx_endpoint_detect: negative size");
+    SRX_REQUIRE(cfg->sample_rate > 0 && cfg->block_ms > 0, "srx_endpoint_detect: sample_rate and block_ms must be positive");
+    const int64_t block = (int64_t)((double)cfg->sample_rate * cfg->block_ms / 1000.0);
+    SRX_REQUIRE(block >= 1 && block < (1 << 24), "srx_endpoint_detect: block of %lld samples", (long long)block);
+    SRX_REQUIRE(max_segments >= 1, "srx_endpoint_detect: max_segments must be >= 1");
+    if (n_recordings == 0) return SRX_OK;
+    SRX_REQUIRE(sample_offsets && block_offsets && out_segments && out_counts && out_thresholds,
+                "srx_endpoint_detect: NULL buffer");
+    SRX_REQUIRE(n_blocks == 0 || (audio && out_energy && out_zcr), "srx_endpoint_detect: NULL buffer");
+    SRX_HIP(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (n_blocks > 0) {
+        int64_t grid = (n_blocks + 15) / 16;
+        const int64_t cap = (int64_t)h->n_cu * 16;
+        if (grid > cap) grid = cap;
+        if (dtype == SRX_F64)
+            hipLaunchKernelGGL(endpoint_blocks_kernel<double>, dim3((unsigned)grid), dim3(256), 0, st,
+                               (const double*)audio, sample_offsets, block_offsets, n_recordings,
+                               n_blocks, (int)block, out_energy, out_zcr);
+        else
+            hipLaunchKernelGGL(endpoint_blocks_kernel<float>, dim3((unsigned)grid), dim3(256), 0, st,
+                               (const float*)audio, sample_offsets, block_offsets, n_recordings,
+                               n_blocks, (int)block, out_energy, out_zcr);
+    }
+    const unsigned g2 = (unsigned)((n_recordings + 63) / 64);
+    hipLaunchKernelGGL(endpoint_detect_kernel, dim3(g2), dim3(64), 0, st, out_energy, out_zcr,
+                       block_offsets, n_recordings, *cfg, (int)block, (int)max_segments,
+                       out_segments, out_counts, out_thresholds);
+    SRX_HIP(hipGetLastError());
+    return SRX_OK;
+}
+
+}  // extern "C"

@@ -26,6 +26,11 @@ def posteriors_golden():
 
 
 @pytest.fixture(scope="session")
+def endpoint_golden():
+    return np.load(os.path.join(GOLDEN, "endpoint_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def mfcc_golden():
     return np.load(os.path.join(GOLDEN, "mfcc_golden.npz"))
 

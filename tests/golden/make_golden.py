@@ -2,7 +2,7 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_golden.py [mfcc] [hmm] [folds] [post]
+    python tests/golden/make_golden.py [mfcc] [hmm] [folds] [post] [endpoint]
 
 The reference modules are imported as they are.  ``mfcc.py`` imports three
 third-party modules that are absent here and that the code path never uses for
@@ -202,6 +202,74 @@ def make_posteriors(ref_hmm):
     print("posteriors_golden.npz:", sorted(data))
 
 
+def _endpoint_chunks():
+    """Synthetic 1 s chunks (quiet background, loud tone bursts, hiss around some of the
+    bursts) plus 1 s chunks of two of the reference's raw recordings."""
+    from scipy.io import wavfile
+    rng = np.random.default_rng(515)
+    out = []
+
+    def chunk(fs, parts, seconds=1.0, floor=0.0005):
+        n = int(seconds * fs)
+        t = np.arange(n) / fs
+        x = floor * rng.standard_normal(n)
+        for kind, a, b, amp in parts:
+            i, j = int(a * fs), int(b * fs)
+            if kind == "tone":
+                x[i:j] += amp * np.sin(2 * np.pi * 180.0 * t[i:j]) * (1 + 0.3 * np.sin(2 * np.pi * 7 * t[i:j]))
+            else:   # hiss: many zero crossings, little energy
+                x[i:j] += amp * rng.standard_normal(j - i)
+        return x.astype(np.float32), fs
+
+    out.append(chunk(22050, [("tone", 0.35, 0.65, 0.3)]))
+    out.append(chunk(22050, [("tone", 0.15, 0.35, 0.3), ("tone", 0.6, 0.85, 0.25)]))
+    out.append(chunk(22050, [("tone", 0.35, 0.65, 0.3)], floor=0.004))       # loud background
+    out.append(chunk(22050, [("tone", 0.0, 0.2, 0.3)]))                       # starts in block 0
+    out.append(chunk(22050, [("tone", 0.7, 1.0, 0.3)]))                       # reaches the end
+    out.append(chunk(22050, []))                                              # background only
+    out.append(chunk(22050, [("tone", 0.5, 0.54, 0.3)]))                      # too short a burst
+    out.append(chunk(22050, [("hiss", 0.22, 0.4, 0.03), ("tone", 0.4, 0.6, 0.3), ("hiss", 0.6, 0.8, 0.03)]))
+    out.append(chunk(16000, [("tone", 0.3, 0.5, 0.3), ("hiss", 0.5, 0.62, 0.04)]))
+    out.append(chunk(16000, [("tone", 0.2, 0.5, 0.3), ("tone", 1.2, 1.9, 0.2), ("hiss", 1.9, 2.1, 0.03)], seconds=2.5))
+    out.append(chunk(22050, [("tone", 0.0, 0.03, 0.3), ("tone", 0.4, 0.7, 0.3)]))   # short run in block 0
+    for name in ("play_music_12", "what_time_is_it_27"):
+        fs, x = wavfile.read(f"{REF}/Recordings_3005/{name}.wav")
+        x = np.asarray(x, dtype=np.float32)
+        for i in range(0, len(x), fs):
+            out.append((x[i:i + fs], fs))
+    return out
+
+
+def make_endpoint():
+    """AudioMonitor.start_saved_audio + combine_audio of new_speech_detect.py on each
+    chunk.  The module imports audio / GUI / hmmlearn packages that are absent here and
+    that this code path never calls: empty placeholder modules stand in for the
+    import."""
+    for name in ("pyautogui", "hmmlearn", "hmmlearn.hmm", "soundfile"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["hmmlearn"].hmm = sys.modules["hmmlearn.hmm"]
+    import new_speech_detect as nsd
+    data = {}
+    chunks = _endpoint_chunks()
+    for i, (x, fs) in enumerate(chunks):
+        mon = nsd.AudioMonitor(device=0, fs=fs)
+        x64 = x.astype(np.float64)
+        th = mon.start_saved_audio(x64)
+        data[f"x{i}"], data[f"fs{i}"] = x, np.int64(fs)
+        data[f"energy{i}"] = np.array(mon.energies, dtype=np.float64)
+        data[f"zcr{i}"] = np.array(mon.zcrs, dtype=np.float64)
+        speech = len(th) > 0 and th[0][0][-1] > 0
+        segs = np.array(th[0], dtype=np.int64).reshape(-1, 4) if speech else np.zeros((0, 4), np.int64)
+        data[f"segs{i}"] = segs
+        data[f"thr{i}"] = np.array(th[1:4], dtype=np.float64) if speech else np.zeros(3)
+        cut = mon.combine_audio(x64, th[0], fs) if speech else np.zeros(0)
+        data[f"cut{i}"] = np.asarray(cut, dtype=np.float32)
+        print(i, fs, len(x), "segments", segs.tolist(), "thr", data[f"thr{i}"], "cut", len(data[f"cut{i}"]))
+    data["n"] = np.int64(len(chunks))
+    np.savez_compressed(os.path.join(OUT, "endpoint_golden.npz"), **data)
+    print("endpoint_golden.npz:", len(chunks), "chunks")
+
+
 def fold_init(X, S):
     """Deterministic initial parameters for the fold fixtures (the reference's
     own init draws from unseeded global RNG state, hmm.py:120-127)."""
@@ -275,7 +343,7 @@ def make_folds(ref_final, ref_hmm, n_iter=8):
 
 
 if __name__ == "__main__":
-    what = set(sys.argv[1:]) or {"mfcc", "hmm", "folds", "post"}
+    what = set(sys.argv[1:]) or {"mfcc", "hmm", "folds", "post", "endpoint"}
     ref_mfcc, ref_final, ref_hmm, ref_utils = _import_reference()
     if "mfcc" in what:
         make_mfcc(ref_mfcc, ref_final)
@@ -283,5 +351,7 @@ if __name__ == "__main__":
         make_hmm(ref_hmm, ref_utils)
     if "post" in what:
         make_posteriors(ref_hmm)
+    if "endpoint" in what:
+        make_endpoint()
     if "folds" in what:
         make_folds(ref_final, ref_hmm)

@@ -472,3 +472,77 @@ def test_model_class_posterior_surface(sra, hmm_golden, posteriors_golden):
     Xs2, states2 = m.sample(25, random_state=np.random.RandomState(3))
     np.testing.assert_array_equal(Xs, Xs2)
     np.testing.assert_array_equal(states, states2)
+
+
+# ------------------------------------------------------------------ end-pointing
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_endpoint_batch_matches_reference(sra, ctx, endpoint_golden, dtype):
+    """All fixture chunks of one sample rate as one batch: block energies (1e-12
+    relative; float32 input is accumulated in float64 like the float64 reference run),
+    zero-crossing counts, segments and thresholds of the reference's AudioMonitor."""
+    g = endpoint_golden
+    for fs in (22050, 16000):
+        idx = [i for i in range(int(g["n"])) if int(g[f"fs{i}"]) == fs]
+        sigs = [g[f"x{i}"] for i in idx]
+        so = np.concatenate([[0], np.cumsum([len(s) for s in sigs])])
+        res = sra.endpoint.detect_batch(np.concatenate(sigs), so, fs, dtype=dtype, ctx=ctx)
+        energy, zcr = res.energy.cpu().numpy(), res.zcr.cpu().numpy()
+        segs, thr = res.segments_host(), res.thresholds.cpu().numpy()
+        bo = res.block_offsets
+        for k, i in enumerate(idx):
+            np.testing.assert_allclose(energy[bo[k]:bo[k + 1]], g[f"energy{i}"], rtol=1e-12)
+            np.testing.assert_array_equal(zcr[bo[k]:bo[k + 1]], g[f"zcr{i}"].astype(np.int32))
+            assert np.array_equal(np.array(segs[k], dtype=np.int64).reshape(-1, 4), g[f"segs{i}"]), (i, segs[k])
+            if len(segs[k]):
+                np.testing.assert_allclose(thr[k], g[f"thr{i}"], rtol=1e-12)
+        # the speech pieces, cut on the device
+        packed, new_so, _ = sra.endpoint.cut_batch(np.concatenate(sigs), so, fs, dtype=dtype, ctx=ctx)
+        packed = packed.cpu().numpy()
+        for k, i in enumerate(idx):
+            np.testing.assert_array_equal(packed[new_so[k]:new_so[k + 1]].astype(np.float32), g[f"cut{i}"])
+
+
+def test_endpoint_class_surface_and_random_chunks(sra, ctx, endpoint_golden):
+    """AudioMonitor.start_saved_audio / combine_audio in the reference's formats, and
+    a seeded batch of random burst patterns (ragged lengths, an empty and a 3-sample
+    recording) against the oracle."""
+    from oracle import endpoint_oracle as eo
+    g = endpoint_golden
+    for i in (4, 5, 6, 9, 12):
+        x, fs = g[f"x{i}"].astype(np.float64), int(g[f"fs{i}"])
+        mon = sra.endpoint.AudioMonitor(device=0, fs=fs, ctx=ctx)
+        th = mon.start_saved_audio(x)
+        if len(g[f"segs{i}"]):
+            assert th[0] == g[f"segs{i}"].tolist()
+            np.testing.assert_allclose(th[1:], g[f"thr{i}"], rtol=1e-12)
+            np.testing.assert_array_equal(np.asarray(mon.combine_audio(x, th[0], fs), dtype=np.float32),
+                                          g[f"cut{i}"])
+        else:
+            assert th == [] or th[0] == [[0, 0, 0, 0]]
+        np.testing.assert_allclose(mon.energies, g[f"energy{i}"], rtol=1e-12)
+    rng = np.random.default_rng(99)
+    fs = 16000
+    sigs = []
+    for r in range(40):
+        n = int(rng.integers(2000, 40000))
+        x = rng.uniform(0.0002, 0.002) * rng.standard_normal(n)
+        for _ in range(int(rng.integers(0, 4))):
+            a = int(rng.integers(0, n))
+            b = min(n, a + int(rng.integers(200, 9000)))
+            x[a:b] += rng.uniform(0.05, 0.4) * np.sin(2 * np.pi * rng.uniform(100, 3000) * np.arange(b - a) / fs)
+        sigs.append(x)
+    sigs.insert(7, np.zeros(0))
+    sigs.insert(20, np.array([0.1, -0.1, 0.1]))
+    so = np.concatenate([[0], np.cumsum([len(s) for s in sigs])])
+    res = sra.endpoint.detect_batch(np.concatenate(sigs), so, fs, dtype="float64", ctx=ctx, max_segments=32)
+    segs, thr = res.segments_host(), res.thresholds.cpu().numpy()
+    found = 0
+    for k, x in enumerate(sigs):
+        if len(x) == 0:
+            assert segs[k] == []
+            continue
+        ref_segs, itu, itl, izct = eo.detect(x, fs)
+        assert segs[k] == ref_segs, (k, segs[k], ref_segs)
+        found += len(ref_segs)
+        np.testing.assert_allclose(thr[k], [itu, itl, izct], rtol=1e-11)
+    assert found >= 20

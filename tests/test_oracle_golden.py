@@ -103,6 +103,26 @@ def test_viterbi_matches_reference(hmm_golden, case):
     np.testing.assert_array_equal(path, g[p + "vit_path"])
 
 
+def test_endpoint_oracle_matches_reference(endpoint_golden):
+    """Block energies / zero crossings, thresholds, segments and the cut signal of every
+    fixture chunk (outputs of the reference's AudioMonitor)."""
+    from oracle import endpoint_oracle as eo
+    g = endpoint_golden
+    n_speech = 0
+    for i in range(int(g["n"])):
+        x, fs = g[f"x{i}"].astype(np.float64), int(g[f"fs{i}"])
+        energy, zcr = eo.block_features(x, eo.block_size(fs))
+        np.testing.assert_allclose(energy, g[f"energy{i}"], rtol=1e-12)
+        np.testing.assert_array_equal(zcr, g[f"zcr{i}"])
+        segs, itu, itl, izct = eo.detect(x, fs)
+        assert np.array_equal(np.array(segs, dtype=np.int64).reshape(-1, 4), g[f"segs{i}"])
+        if len(segs):
+            n_speech += 1
+            np.testing.assert_allclose([itu, itl, izct], g[f"thr{i}"], rtol=1e-12)
+        np.testing.assert_array_equal(eo.combine(x, segs, fs).astype(np.float32), g[f"cut{i}"])
+    assert n_speech >= 10
+
+
 def test_split_lengths_error():
     with pytest.raises(ValueError):
         ho.split_lengths(np.zeros((5, 2)), [2, 2])
