@@ -225,7 +225,19 @@ def main():
                          "ms": dtf * 1e3,
                          "hbm_frac": raw_frames * 796 / dtf / 1e9 / HBM_PEAK_GBS,
                          "config": "16 kHz, 400/160 samples, 512-pt FFT, 40 mel, 13 MFCC+d+dd, z-score"}
-        del audio, feats
+        # end-pointing pre-pass over the same recordings (10 ms block energies and
+        # zero crossings, thresholds, run search)
+        ep = sra.endpoint.detect_batch(audio, so, 16000, ctx=ctx)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ep = sra.endpoint.detect_batch(audio, so, 16000, ctx=ctx)
+        barrier()
+        dte = (time.perf_counter() - t0) / reps
+        extra["endpoint"] = {"samples_per_s": n_utt_fe * n_samp * world / dte, "ms": dte * 1e3,
+                             "hbm_frac": n_utt_fe * n_samp * 4 / dte / 1e9 / HBM_PEAK_GBS,
+                             "config": "8192 recordings x 3 s at 16 kHz, float32 (4 B in per sample)"}
+        del audio, feats, ep
         torch.cuda.empty_cache()
         # Baum-Welch: 6 models x 16 states, utterance u trains model u mod 6
         Ut = args.train_utts if args.train_utts > 0 else (1 << 20) // world

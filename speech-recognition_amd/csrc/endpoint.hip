@@ -6,7 +6,7 @@
 //                            number of sign changes inside the block.  One pass over
 //                            the samples: 4 (or 8) bytes read per sample, 12 bytes
 //                            written per block.
-//   endpoint_detect_kernel   one thread per recording: peak / floor energies, the
+//   endpoint_detect_kernel   16 lanes per recording: peak / floor energies, the
 //                            three thresholds, the sequential run search over the
 //                            recording's blocks, widening by the zero-crossing rule.
 #include "srx_internal.h"
@@ -14,6 +14,17 @@
 #include <math.h>
 
 namespace {
+
+// Value of lane (j + 1) mod 16 of the same row of 16 lanes (DPP row rotation: no LDS).
+__device__ __forceinline__ float rot1(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x12F, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double rot1(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x12F, 0xF, 0xF, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x12F, 0xF, 0xF, false);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void endpoint_blocks_kernel(
@@ -23,30 +34,46 @@ __global__ __launch_bounds__(256) void endpoint_blocks_kernel(
     const int j = threadIdx.x & 15;
     const int64_t sub = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int64_t nsub = ((int64_t)gridDim.x * blockDim.x) >> 4;
-    // the recording under a block advances monotonically with the block index
-    int64_t rec = 0;
+    // The recording under a block advances monotonically with the block index: its
+    // bounds stay in registers and are looked up again only when a block leaves them.
+    int64_t rec = 0, b_lo = 0, b_hi = 0, s_lo = 0, s_hi = 0;
+    constexpr int kBatch = 10;                 // loads in flight per lane (160 samples = 1 batch)
     for (int64_t b = sub; b < n_blocks; b += nsub) {
-        // recording of block b: last rec with bo[rec] <= b (binary search from the
-        // previous position)
-        if (!(bo[rec] <= b && b < bo[rec + 1])) {
-            int64_t lo = rec, hi = n_rec;
-            if (bo[rec] > b) lo = 0;
+        if (!(b_lo <= b && b < b_hi)) {
+            int64_t lo = b >= b_lo ? rec : 0, hi = n_rec;
             while (hi - lo > 1) {
                 const int64_t mid = (lo + hi) >> 1;
                 if (bo[mid] <= b) lo = mid; else hi = mid;
             }
             rec = lo;
+            b_lo = bo[rec];
+            b_hi = bo[rec + 1];
+            s_lo = so[rec];
+            s_hi = so[rec + 1];
         }
-        const int64_t s_begin = so[rec] + (b - bo[rec]) * block;
-        const int64_t s_end = so[rec + 1];
-        const int len = (int)(s_end - s_begin < block ? s_end - s_begin : block);
+        const int64_t s_begin = s_lo + (b - b_lo) * block;
+        const int len = (int)(s_hi - s_begin < block ? s_hi - s_begin : block);
         const T* x = audio + s_begin;
         double e = 0.0;
         int z = 0;
-        for (int i = j; i < len; i += 16) {
-            const T v = x[i];
-            e += (double)fabs(v);
-            if (i + 1 < len) z += (v >= (T)0) != (x[i + 1] >= (T)0);
+        // lane j takes samples j, j + 16, ...: the sample after lane j's is lane j+1's of
+        // the same round, or lane 0's of the next round
+        for (int base = 0; base < len; base += 16 * kBatch) {
+            T v[kBatch + 1];
+#pragma unroll
+            for (int q = 0; q <= kBatch; ++q) {
+                const int i = base + 16 * q + j;
+                v[q] = i < len && (q < kBatch || j == 0) ? x[i] : (T)0;
+            }
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q) {
+                const int i = base + 16 * q + j;
+                const T nxt_same = rot1(v[q]);
+                const T nxt_round = rot1(v[q + 1]);
+                const T nx = j == 15 ? nxt_round : nxt_same;
+                e += (double)fabs(v[q]);
+                z += (i + 1 < len) && ((v[q] >= (T)0) != (nx >= (T)0));
+            }
         }
 #pragma unroll
         for (int o = 8; o >= 1; o >>= 1) {
@@ -66,7 +93,11 @@ __global__ void endpoint_detect_kernel(const double* __restrict__ energy,
                                        srx_endpoint_cfg_t c, int block, int max_seg,
                                        int32_t* __restrict__ segs, int32_t* __restrict__ counts,
                                        double* __restrict__ thr) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // 16 lanes per recording: they load 16 blocks at a time and all walk the same
+    // sequential search on values passed round by shuffles (no lane waits on memory
+    // for every single block); lane 0 of the group writes.
+    const int j = threadIdx.x & 15;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     if (r >= n_rec) return;
     const int64_t b0 = bo[r];
     const int n = (int)(bo[r + 1] - b0);
@@ -74,15 +105,22 @@ __global__ void endpoint_detect_kernel(const double* __restrict__ energy,
     const int32_t* z = zcr + b0;
     int32_t* out = segs + r * (int64_t)max_seg * 4;
     double* t = thr + r * 3;
-    counts[r] = 0;
-    t[0] = t[1] = t[2] = 0.0;
+    if (j == 0) {
+        counts[r] = 0;
+        t[0] = t[1] = t[2] = 0.0;
+    }
     if (n <= 0) return;
     double imx = e[0], imn = e[0];
-    for (int i = 1; i < n; ++i) {
+    for (int i = j; i < n; i += 16) {
         imx = fmax(imx, e[i]);
         imn = fmin(imn, e[i]);
     }
-    t[0] = imx;                                  // (reported when nothing is found)
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) {
+        imx = fmax(imx, __shfl_xor(imx, o, 16));
+        imn = fmin(imn, __shfl_xor(imn, o, 16));
+    }
+    if (j == 0) t[0] = imx;                      // (reported when nothing is found)
     if (imx < c.noise_peak) return;
     const double itl = fmin(0.03 * (imx - imn) + imn, 4.0 * imn);
     const double itu = 5.0 * itl;
@@ -119,7 +157,7 @@ __global__ void endpoint_detect_kernel(const double* __restrict__ energy,
                 ++hits;
             }
         const int n2p = hits >= 3 ? last_hit : n2;
-        if (cnt < max_seg) {
+        if (cnt < max_seg && j == 0) {
             out[4 * cnt + 0] = n1p - 10 > 0 ? n1p - 10 : 0;
             out[4 * cnt + 1] = n1;
             out[4 * cnt + 2] = n2;
@@ -127,8 +165,12 @@ __global__ void endpoint_detect_kernel(const double* __restrict__ energy,
         }
         ++cnt;
     };
-    for (int i = 0; i < n; ++i) {
-        const double v = e[i];
+    for (int base = 0; base < n; base += 16) {
+      const double mine = base + j < n ? e[base + j] : 0.0;
+      const int lim = n - base < 16 ? n - base : 16;
+      for (int k = 0; k < lim; ++k) {
+        const int i = base + k;
+        const double v = __shfl(mine, k, 16);
         if (v > itu) {
             if (u0 == -1) u0 = i;
             ++uc;
@@ -159,7 +201,9 @@ __global__ void endpoint_detect_kernel(const double* __restrict__ energy,
             l0 = -1;
             ld = 0;
         }
+      }
     }
+    if (j != 0) return;
     counts[r] = cnt;
     if (cnt > 0) {
         t[0] = itu;
@@ -210,8 +254,8 @@ int srx_endpoint_detect(srx_handle_t h, const void* audio, int dtype, const int6
                                (const float*)audio, sample_offsets, block_offsets, n_recordings,
                                n_blocks, (int)block, out_energy, out_zcr);
     }
-    const unsigned g2 = (unsigned)((n_recordings + 63) / 64);
-    hipLaunchKernelGGL(endpoint_detect_kernel, dim3(g2), dim3(64), 0, st, out_energy, out_zcr,
+    const unsigned g2 = (unsigned)((n_recordings + 15) / 16);
+    hipLaunchKernelGGL(endpoint_detect_kernel, dim3(g2), dim3(256), 0, st, out_energy, out_zcr,
                        block_offsets, n_recordings, *cfg, (int)block, (int)max_segments,
                        out_segments, out_counts, out_thresholds);
     SRX_HIP(hipGetLastError());

@@ -8,7 +8,7 @@ OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"
 cd /tmp
 export TMPDIR=/tmp
-for name in estep mfcc viterbi emission large posteriors; do
+for name in estep mfcc viterbi emission large posteriors endpoint; do
   timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$name" -o "$name" -- python3 "$ROOT/tools/${name}_bench.py" > "$OUT/prof_$name.log" 2>&1
 done
 ls "$OUT"/prof_*/*_kernel_stats.csv
