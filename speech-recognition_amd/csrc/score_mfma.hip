@@ -628,9 +628,9 @@ int srx_mfma_emission_utt_f32(srx_context* h, const void* X, const int64_t* off,
 int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
                    const srx_models_t* md, double* out, hipStream_t st) {
     const int M = md->n_models, S = md->n_states, D = md->n_features;
-    if (S > 8 || D > 48 || n_frames <= 0) return SRX_EUNSUPPORTED;
-    if (h->exact_f32 && D > 40) return SRX_EUNSUPPORTED;
-    const int SP = S <= 4 ? 4 : 8;
+    if (S > 16 || D > 48 || n_frames <= 0) return SRX_EUNSUPPORTED;
+    if (h->exact_f32 && (D > 40 || S > 8)) return SRX_EUNSUPPORTED;
+    const int SP = S <= 4 ? 4 : (S <= 8 ? 8 : 16);
     const int NT = (M * SP + 15) / 16;
     int R = (D + 7) / 8;
     if (R == 3) R = 4;
@@ -655,6 +655,8 @@ int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
         hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, SP, NTP, RQ, H, base,
                            cst, A, pi);
         const float* Xf = (const float*)X;
+        if (SP == 16)
+            return srx_split_score_sp16(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st);
         return SP == 8 ? srx_split_score_sp8(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st)
                        : srx_split_score_sp4(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st);
     }

@@ -30,6 +30,19 @@ __device__ __forceinline__ float pair_sum(float v) {
     const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// The same over all four 16-lane rows (a model of 9..16 states fills a whole tile).
+__device__ __forceinline__ float quad_max(float v) {
+    v = pair_max(v);
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v = pair_sum(v);
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 
 // ---------------------------------------------------------------------------
@@ -319,6 +332,7 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
         for (int nt = 0; nt < NT; ++nt) {
             mx[nt] = fmaxf(fmaxf(acc[nt][0], acc[nt][1]), fmaxf(acc[nt][2], acc[nt][3]));
             if (SP == 8) mx[nt] = pair_max(mx[nt]);
+            if (SP == 16) mx[nt] = quad_max(mx[nt]);
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -355,6 +369,7 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
         for (int nt = 0; nt < NT; ++nt) {
             c[nt] = (na[nt][0] + na[nt][1]) + (na[nt][2] + na[nt][3]);
             if (SP == 8) c[nt] = pair_sum(c[nt]);
+            if (SP == 16) c[nt] = quad_sum(c[nt]);
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -426,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
     if (valid) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const bool writer = SP == 4 ? true : (g & 1) == 0;
+            const bool writer = SP == 4 ? true : (SP == 8 ? (g & 1) == 0 : g == 0);
             // a batch spanning 4 GiB or more cannot be addressed: report NaN, not garbage
             if (writer && model[nt] < M)
                 out[u * M + model[nt]] = span_ok ? lp[nt] * kLn2 : __builtin_nan("");
@@ -474,7 +489,7 @@ void launch_split(const float* X, const int64_t* off, int64_t U, int64_t n_frame
 
 }  // namespace
 
-// Scoring dispatch for one padded state count (SP = 8: score_split8.hip, SP = 4:
+// Scoring dispatch for one padded state count (SP = 16: score_split16.hip, SP = 8: score_split8.hip, SP = 4:
 // score_split4.hip).  RQ full 16-feature blocks, H = 1 for an 8-feature tail; the
 // bank's tiles are taken NT at a time by `chunks` slices of the grid (the tables
 // hold chunks * NT tiles).
@@ -484,3 +499,6 @@ int srx_split_score_sp8(const float* X, const int64_t* off, int64_t U, int64_t n
 int srx_split_score_sp4(const float* X, const int64_t* off, int64_t U, int64_t n_frames, int M,
                         int S, int D, int NT, int chunks, int RQ, int H, const unsigned* Wp, const float* cst,
                         const float* A, const float* pi, double* out, hipStream_t st);
+int srx_split_score_sp16(const float* X, const int64_t* off, int64_t U, int64_t n_frames, int M,
+                         int S, int D, int NT, int chunks, int RQ, int H, const unsigned* Wp, const float* cst,
+                         const float* A, const float* pi, double* out, hipStream_t st);

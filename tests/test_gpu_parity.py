@@ -391,11 +391,13 @@ def test_cross_validate_batched_matches_reference(sra, ctx, folds_golden, dtype)
             np.testing.assert_allclose(A[m], g[q + "A"], rtol=1e-5 if tight else 1e-3, atol=1e-9 if tight else 1e-5)
 
 
-@pytest.mark.parametrize("M,S,D", [(30, 3, 26), (12, 8, 39), (7, 8, 13), (13, 5, 39), (50, 4, 20)])
+@pytest.mark.parametrize("M,S,D", [(30, 3, 26), (12, 8, 39), (7, 8, 13), (13, 5, 39), (50, 4, 20),
+                                   (1, 16, 39), (6, 16, 39), (3, 9, 13), (7, 12, 26), (2, 16, 48)])
 def test_scoring_banks_larger_than_three_tiles(sra, ctx, M, S, D):
     """More state rows than one pass of the matrix-core kernel holds (3 tiles of
     16): the bank is scored in slices of the grid, same results as the
-    shape-generic kernels and the oracle."""
+    shape-generic kernels and the oracle.  Models of 9 to 16 states take a whole tile
+    each."""
     rng = np.random.default_rng(M * 100 + S)
     prms = [ho.random_params(rng, S, D) for _ in range(M)]
     lengths = [1, 2, 50, 17, 33, 64, 3, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 5]
