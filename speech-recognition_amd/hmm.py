@@ -3,7 +3,8 @@
 ``MyGaussianHMM`` keeps the constructor, attributes and methods of
 ``my_hmmlearn.hmm.MyGaussianHMM`` (my_hmmlearn/hmm.py:73-451), which is
 itself duck-typed to ``hmmlearn.hmm.GaussianHMM`` as ``HMM_lib.py:33`` uses it
-(``GaussianHMM`` below is the same class).  Parameters live on the host as
+(``GaussianHMM`` below adds hmmlearn's own initialisation and switches on top of
+it).  Parameters live on the host as
 numpy arrays, like the reference's; scoring, the E-step, the M-step and
 Viterbi run in libsrx kernels.
 
@@ -308,4 +309,96 @@ class MyGaussianHMM:
         return self
 
 
-GaussianHMM = MyGaussianHMM
+class GaussianHMM(MyGaussianHMM):
+    """``hmmlearn.hmm.GaussianHMM`` as ``HMM_lib.py:33-34`` constructs and uses it
+    (``GaussianHMM(n_components=3, tol=1e-4, n_iter=2000, implementation="log",
+    verbose=True).fit(X, lengths)``, then ``score``).  hmmlearn is not in the image
+    and the reference pins no output at this boundary, so everything specific to
+    this class -- the initialisation below, ``params`` / ``init_params``, the "map"
+    decoder -- follows hmmlearn 0.3's published behaviour and is parity unpinned;
+    the EM arithmetic is the pinned one of the base class.
+
+    Initialisation (letters of ``init_params``): "s" / "t" uniform start and
+    transition probabilities, "m" the centres of a k-means clustering of the data
+    (scikit-learn, ``random_state``), "c" the data's per-feature variance plus
+    ``min_covar`` for every state.  A letter left out keeps the attribute the caller
+    has set.  ``params`` lists what ``fit`` re-estimates.  The clustering runs on the
+    host: it happens once per fit and is not part of the per-iteration path."""
+
+    def __init__(self, n_components=1, covariance_type="diag", min_covar=1e-3,
+                 startprob_prior=1.0, transmat_prior=1.0, means_prior=0, means_weight=0,
+                 covars_prior=1e-2, covars_weight=1, algorithm="viterbi", random_state=None,
+                 n_iter=10, tol=1e-2, verbose=False, params="stmc", init_params="stmc",
+                 implementation="log", *, dtype="float64", device=None):
+        super().__init__(n_components, covariance_type, min_covar, startprob_prior,
+                         transmat_prior, means_prior, means_weight, covars_prior, covars_weight,
+                         random_state, n_iter, tol, verbose, implementation, mstep="full",
+                         dtype=dtype, device=device)
+        if algorithm not in ("viterbi", "map"):
+            raise ValueError(f"Unknown decoder {algorithm!r}")
+        self.algorithm = algorithm
+        self.params = params
+        self.init_params = init_params
+
+    def init(self, X, lengths=None):
+        from sklearn.cluster import KMeans
+        X = np.asarray(X, dtype=np.float64)
+        self.check_and_set_n_features(X)
+        S = self.n_components
+        if "s" in self.init_params or not hasattr(self, "startprob_"):
+            self.startprob_ = np.full(S, 1.0 / S)
+        if "t" in self.init_params or not hasattr(self, "transmat_"):
+            self.transmat_ = np.full((S, S), 1.0 / S)
+        if "m" in self.init_params or not hasattr(self, "means_"):
+            km = KMeans(n_clusters=S, random_state=self.random_state, n_init=10)
+            self.means_ = np.array(km.fit(X).cluster_centers_, dtype=np.float64)
+        if "c" in self.init_params or not hasattr(self, "_covars_"):
+            cv = np.cov(X.T) + self.min_covar * np.eye(X.shape[1])
+            if not cv.shape:
+                cv = cv.reshape(1, 1)
+            self.covars_ = np.tile(np.diag(cv), (S, 1))
+
+    def fit_from_current(self, X, lengths=None):
+        wanted = set(self.params) & set("stmc")
+        if wanted == set("stmc"):
+            self.mstep = "full"
+            return super().fit_from_current(X, lengths)
+        if wanted == set("st"):
+            self.mstep = "transitions_only"
+            return super().fit_from_current(X, lengths)
+        # any other subset: full re-estimation on the device, the frozen parameters put
+        # back after every iteration
+        data = self._data(X, lengths)
+        pri = self._priors()
+        self.monitor_ = ConvergenceMonitor(self.tol, self.n_iter, self.verbose)
+        for _ in range(self.n_iter):
+            keep = (self.startprob_.copy(), self.transmat_.copy(), self.means_.copy(),
+                    self._covars_.copy())
+            bank = self._bank()
+            stats = bank.estep(data)
+            logprob = float(stats[0, 1].item())
+            bank.mstep(stats, pri, "full")
+            self._pull(bank)
+            if "s" not in wanted:
+                self.startprob_ = keep[0]
+            if "t" not in wanted:
+                self.transmat_ = keep[1]
+            if "m" not in wanted:
+                self.means_ = keep[2]
+            if "c" not in wanted:
+                self._covars_ = keep[3]
+            self.monitor_.report(logprob)
+            if self.monitor_.converged:
+                break
+        return self
+
+    def decode(self, X, lengths=None, algorithm=None):
+        """(log-probability, states): "viterbi" is the base class's decoder; "map"
+        takes the most probable state of every sample from the posteriors."""
+        algorithm = algorithm or self.algorithm
+        if algorithm == "viterbi":
+            return super().decode(X, lengths)
+        if algorithm != "map":
+            raise ValueError(f"Unknown decoder {algorithm!r}")
+        _, post = self.score_samples(X, lengths)
+        return float(np.max(post, axis=1).sum()), np.argmax(post, axis=1)

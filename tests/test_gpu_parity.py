@@ -548,3 +548,50 @@ def test_endpoint_class_surface_and_random_chunks(sra, ctx, endpoint_golden):
         found += len(ref_segs)
         np.testing.assert_allclose(thr[k], [itu, itl, izct], rtol=1e-11)
     assert found >= 20
+
+
+# ------------------------------------------------------------------ hmmlearn-style class
+def test_hmmlearn_style_class(sra, ctx):
+    """GaussianHMM as HMM_lib.py uses it: k-means / variance initialisation, EM from
+    that start equal to the oracle's EM from the same start, params / init_params,
+    the "map" decoder.  (hmmlearn itself is absent: parity with it is unpinned; the EM
+    arithmetic is the pinned one.)"""
+    rng = np.random.default_rng(4)
+    S, D = 3, 13
+    centres = 3.0 * rng.standard_normal((S, D))
+    lengths = [60, 45, 80, 30]
+    states = np.concatenate([np.sort(rng.integers(0, S, size=n)) for n in lengths])
+    X = centres[states] + rng.standard_normal((sum(lengths), D))
+    m = sra.GaussianHMM(n_components=S, tol=1e-4, n_iter=6, implementation="log", random_state=0)
+    m.init(X, lengths)
+    np.testing.assert_allclose(m.startprob_, 1.0 / S)
+    np.testing.assert_allclose(m.transmat_, 1.0 / S)
+    assert np.linalg.norm(m.means_[:, None] - centres[None], axis=2).min(axis=1).max() < 1.5
+    np.testing.assert_allclose(m._covars_, np.tile(X.var(axis=0, ddof=1) + 1e-3, (S, 1)))
+    p = ho.Params(m.startprob_, m.transmat_, m.means_, m._covars_)
+    hist = []
+    for _ in range(6):
+        st, lps = ho.estep(p, X, lengths, loops=False)
+        hist.append(lps.sum())
+        p = ho.mstep_full(p, st)
+        if len(hist) >= 2 and hist[-1] - hist[-2] < 1e-4:
+            break
+    m.fit(X, lengths)
+    np.testing.assert_allclose(list(m.monitor_.history), hist, rtol=1e-9)
+    np.testing.assert_allclose(m.means_, p.means, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(m.transmat_, p.A, rtol=1e-7, atol=1e-12)
+    assert all(b >= a - 1e-6 for a, b in zip(hist, hist[1:]))
+    # params: only the transitions move
+    m2 = sra.GaussianHMM(n_components=S, n_iter=3, params="t", init_params="", random_state=0)
+    m2.startprob_, m2.transmat_, m2.means_, m2._covars_ = (np.full(S, 1 / S), np.full((S, S), 1 / S),
+                                                          p.means.copy(), p.covars.copy())
+    m2.fit(X, lengths)
+    np.testing.assert_array_equal(m2.means_, p.means)
+    np.testing.assert_array_equal(m2.startprob_, np.full(S, 1 / S))
+    assert np.abs(m2.transmat_ - 1 / S).max() > 0.05
+    # decoders
+    lp_v, path_v = m.decode(X, lengths)
+    lp_m, path_m = m.decode(X, lengths, algorithm="map")
+    post = m.predict_proba(X, lengths)
+    np.testing.assert_array_equal(path_m, post.argmax(axis=1))
+    assert np.mean(path_v == path_m) > 0.95
