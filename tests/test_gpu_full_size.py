@@ -165,6 +165,71 @@ def test_viterbi_full_size_properties(sra, ctx):
         assert np.mean(got == rpath) > 0.97
 
 
+def test_posteriors_full_size_properties(sra, ctx):
+    """65,536 x 200 x 39, one 16-state model per utterance: rows of the posteriors sum to
+    one, their sums per model are the E-step's occupation counts, the log-probabilities are
+    the scores, and a sample of utterances agrees with the oracle."""
+    import torch
+    U, T, D, M, S = 65536, 200, 39, 6, 16
+    rng = np.random.default_rng(61)
+    prms = _models(rng, M, S, D)
+    bank = _bank(sra, ctx, prms)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(13)
+    X = torch.randn((U * T, D), device="cuda", dtype=torch.float32, generator=g)
+    off = torch.arange(0, (U + 1) * T, T, device="cuda", dtype=torch.int64)
+    data = sra.Ragged(ctx, X, offsets=off, dtype="float32")
+    um = (np.arange(U) % M).astype(np.int32)
+    um_d = ctx.tensor(um)
+    lp, gam = bank.posteriors(data, um_d)
+    assert bool(torch.isfinite(gam).all()) and float(gam.min()) >= 0.0
+    assert float((gam.sum(dim=1) - 1).abs().max()) < 1e-5
+    sc = bank.score(data)
+    own = sc[torch.arange(U, device="cuda"), torch.from_numpy(um.astype(np.int64)).cuda()]
+    assert float(((lp - own).abs() / own.abs()).max()) < 2e-5
+    st = bank.unpack_stats(bank.estep(data, um_d, None))
+    occ = gam.view(U, T, S).sum(dim=1, dtype=torch.float64).cpu().numpy()
+    for m in range(M):
+        np.testing.assert_allclose(occ[um == m].sum(axis=0), st[m]["post"], rtol=2e-5)
+    for u in rng.choice(U, size=8, replace=False):
+        xu = X[u * T:(u + 1) * T].cpu().numpy().astype(np.float64)
+        rl, rg = ho.score_posteriors(prms[um[u]], xu, [T], loops=False)
+        np.testing.assert_allclose(gam[u * T:(u + 1) * T].cpu().numpy(), rg, rtol=0, atol=2e-5)
+
+
+def test_endpoint_full_size_properties(sra, ctx):
+    """8,192 recordings x 3 s at 16 kHz: a loud stretch in every recording is found where it
+    was put, permuting the recordings permutes the results, and a recording processed alone
+    gives the same blocks and segments as inside the batch."""
+    import torch
+    R, fs = 8192, 16000
+    n = 3 * fs
+    g = torch.Generator(device="cuda")
+    g.manual_seed(17)
+    audio = 0.0005 * torch.randn((R, n), device="cuda", dtype=torch.float32, generator=g)
+    starts = torch.randint(20, 150, (R,), device="cuda", generator=g)          # in blocks of 160
+    lens = torch.randint(30, 120, (R,), device="cuda", generator=g)
+    blk = torch.arange(n, device="cuda") // 160
+    loud = (blk[None, :] >= starts[:, None]) & (blk[None, :] < (starts + lens)[:, None])
+    audio = torch.where(loud, audio * 400.0, audio)
+    so = np.arange(0, (R + 1) * n, n, dtype=np.int64)
+    res = sra.endpoint.detect_batch(audio.reshape(-1), so, fs, ctx=ctx)
+    cnt = res.counts.cpu().numpy()
+    seg = res.segments.cpu().numpy()
+    assert np.all(cnt == 1)
+    np.testing.assert_array_equal(seg[:, 0, 1], starts.cpu().numpy())
+    np.testing.assert_array_equal(seg[:, 0, 2], (starts + lens).cpu().numpy())
+    perm = torch.randperm(R, device="cuda", generator=g)
+    res_p = sra.endpoint.detect_batch(audio[perm].reshape(-1), so, fs, ctx=ctx)
+    assert torch.equal(res_p.segments, res.segments[perm])
+    assert torch.equal(res_p.energy.view(R, -1), res.energy.view(R, -1)[perm])
+    assert torch.equal(res_p.zcr.view(R, -1), res.zcr.view(R, -1)[perm])
+    for r in (0, 4097, R - 1):
+        one = sra.endpoint.detect_batch(audio[r], [0, n], fs, ctx=ctx)
+        assert torch.equal(one.energy, res.energy.view(R, -1)[r])
+        assert torch.equal(one.segments[0], res.segments[r])
+
+
 def test_addressing_beyond_4gib(sra, ctx):
     """262,144 utterances x 200 x 39 floats = 7.6 GiB of features: results for
     utterances past the 4 GiB mark equal those of the same data processed on its own
