@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: batched HMM scoring, 65,536 synthetic utterances x 200
-frames x 39-dim features against 6 word models of 8 states (configs[1] of
-BASELINE.json), on N GPUs of one node (utterances sharded, no collective).
+frames x 39-dim features against 6 word models of 8 states, on N GPUs of one node
+(utterances sharded, no collective).
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -11,9 +11,10 @@ in HBM.  Rank 0 prints ONE JSON line.  Beside the headline it carries
   roofline      algorithmic HBM bytes (156 B/frame in + 48 B/utterance out)
                 / event-timed duration of the scoring launch, against 8 TB/s
   cpu_baseline  the loop-faithful fp64 CPU oracle on a bounded sample
-  extra         front-end frames/s (16 kHz, 512-pt FFT, 40 mel, 39-dim) and
-                Baum-Welch iterations/s (6 models x 16 states), each with its
-                own size, measured outside the timed region of the headline.
+  extra         front-end frames/s (16 kHz, 512-pt FFT, 40 mel, 39-dim), Baum-Welch
+                iterations/s (6 models x 16 states), emission, Viterbi, posteriors,
+                end-pointing and the large-model lines, each with its own size,
+                measured outside the timed region of the headline.
 """
 import argparse
 import json
