@@ -193,6 +193,11 @@ int srx_posteriors(srx_handle_t h, const void* X, int dtype, const int64_t* utt_
     SRX_REQUIRE(out_logprob != nullptr && (n_frames == 0 || out_posteriors != nullptr),
                 "srx_posteriors: NULL output");
     SRX_HIP(hipSetDevice(h->device));
+    if (dtype == SRX_F32 && n_frames > 0) {
+        rc = srx_fused_posteriors(h, X, utt_offsets, n_utts, n_frames, utt_model, models,
+                                  (float*)out_posteriors, out_logprob, (hipStream_t)stream);
+        if (rc != SRX_EUNSUPPORTED) return rc;
+    }
     return srx_generic_posteriors(h, X, dtype, utt_offsets, n_utts, n_frames, utt_model, models,
                                   out_posteriors, out_logprob, (hipStream_t)stream);
 }

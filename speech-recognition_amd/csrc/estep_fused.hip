@@ -163,12 +163,16 @@ struct Frame {
     u32x2 h;
 };
 
-template <int RQ, int H, int NTX>
+// POST = true is the posteriors variant of the same forward-backward pass: gamma of
+// every frame goes to post_out[frame][state] and the utterance's log-probability to
+// post_lp[utterance]; the accumulating products and the statistics are left out.
+template <int RQ, int H, int NTX, bool POST = false>
 __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
     const float* __restrict__ X, const int64_t* __restrict__ off, int64_t U, int64_t n_frames,
     const int32_t* __restrict__ utt_model, const int64_t* __restrict__ utt_order, int M, int S,
     int D, FusedTables tb, const int64_t* __restrict__ batch_base, float* __restrict__ lat,
-    float* __restrict__ scale, double* __restrict__ replicas, int rec_size) {
+    float* __restrict__ scale, double* __restrict__ replicas, int rec_size,
+    float* __restrict__ post_out, double* __restrict__ post_lp) {
     constexpr int DP = 16 * RQ + 8 * H;   // padded feature count
     constexpr int KW = 8 * RQ + 4 * H;    // emission k-steps
     constexpr int XS = frame_tile_stride(DP);
@@ -270,6 +274,11 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
             const __amdgpu_buffer_rsrc_t rsrc_lat = make_rsrc(lat + row_base * 16, (n_frames - row_base) * 64);
             const __amdgpu_buffer_rsrc_t rsrc_sc = make_rsrc(scale + row_base, (n_frames - row_base) * 4);
             const int64_t f0 = active ? f_start : fmin;
+            // (posteriors: rows of S floats, within the same reach as the rows of X)
+            const __amdgpu_buffer_rsrc_t rsrc_post =
+                make_rsrc(POST ? post_out + fmin * S : nullptr,
+                          POST && span_ok ? (n_frames - fmin) * (int64_t)S * 4 : 0);
+            const unsigned post_row = (unsigned)((f0 - fmin) * S * 4);
             const unsigned lane_off = (unsigned)((f0 - fmin) * D * 4) + 16u * g;   // + 64 q for block q
             const unsigned half_off = (unsigned)((f0 - fmin) * D * 4) + 64u * RQ + 8u * g;
             auto loadx = [&](int t, frame_t& dst) {
@@ -390,9 +399,11 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                 loadb(Tmax - 1 - i, xq[i], alq[i], ciq[i]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // the first consume reads buffer 1: start it from zeros
-            for (int i = lane; i < TILE / 4; i += 64) ((f32x4*)(tiles + TILE))[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            wave_sync();
+            if constexpr (!POST) {
+                // the first consume reads buffer 1: start it from zeros
+                for (int i = lane; i < TILE / 4; i += 64) ((f32x4*)(tiles + TILE))[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                wave_sync();
+            }
 
             // (tile reads are issued as a group ahead of the MFMAs that use them)
             auto consume = [&](const float* tl) {
@@ -450,33 +461,46 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                 float gs = sum16(gam);
                 if (gs == 0.f) gs = 1.f;          // utils.normalize: zero rows divide by 1
                 gam = gam * __builtin_amdgcn_rcpf(gs);
-                *(f32x4*)(t_gam + ul * 16 + wsw) = gam;
-                *(f32x4*)(t_alp + ul * 16 + wsw) = al;
-                *(f32x4*)(t_bb + ul * 16 + wsw) = bb;
+                if constexpr (POST) {
+                    // register q of lane group g is state 4q + g
 #pragma unroll
-                for (int q = 0; q < RQ; ++q) {
-                    // (a finished utterance keeps its last frame here: its gamma is 0)
-                    *(u32x4*)(t_x + ul * XS + 16 * q + wsw) = xc.v[q];
+                    for (int q = 0; q < 4; ++q)
+                        __builtin_amdgcn_raw_buffer_store_b32(
+                            __float_as_uint(gam[q]), rsrc_post,
+                            live && 4 * q + g < S ? post_row + (unsigned)t * (unsigned)(S * 4) + (unsigned)(4 * q + g) * 4u
+                                                  : kDrop, 0, 0);
+                } else {
+                    *(f32x4*)(t_gam + ul * 16 + wsw) = gam;
+                    *(f32x4*)(t_alp + ul * 16 + wsw) = al;
+                    *(f32x4*)(t_bb + ul * 16 + wsw) = bb;
+#pragma unroll
+                    for (int q = 0; q < RQ; ++q) {
+                        // (a finished utterance keeps its last frame here: its gamma is 0)
+                        *(u32x4*)(t_x + ul * XS + 16 * q + wsw) = xc.v[q];
+                    }
+                    if constexpr (H != 0) {
+                        *(u32x2*)(t_x + ul * XS + 16 * RQ + hsw) = xc.h;
+                    }
+                    post += gam;
+                    if (t == 0) start = gam;
                 }
-                if constexpr (H != 0) {
-                    *(u32x2*)(t_x + ul * XS + 16 * RQ + hsw) = xc.h;
-                }
-                post += gam;
-                if (t == 0) start = gam;
                 bb = live ? b * beta : f32x4{0.f, 0.f, 0.f, 0.f};
             };
             for (int t0 = Tmax - 1; t0 >= 0; t0 -= 2) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int t = t0 - i;             // t = -1: a dead step, writes zero tiles
-                    consume(tiles + TILE * (i ^ 1));
+                    if constexpr (!POST) consume(tiles + TILE * (i ^ 1));
                     produce(t, tiles + TILE * i, xq[i], alq[i], ciq[i]);
                     loadb(t - 2, xq[i], alq[i], ciq[i]);
-                    wave_sync();
+                    if constexpr (!POST) wave_sync();
                 }
             }
-            consume(tiles + TILE);                    // the last step produced
+            if constexpr (!POST) consume(tiles + TILE);   // the last step produced
 
+            if constexpr (POST) {
+                if (active && g == 0) post_lp[u] = span_ok ? lp * kLn2 : __builtin_nan("");
+            } else {
             // ---------------- batch sums -> this wave's global float64 record
             // G and O are in accumulator layout: lane (g, ul) holds rows 4g+reg, column ul.
             double* dst = my_rep + (size_t)m_cur * rec_size;
@@ -510,6 +534,7 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                     unsafeAtomicAdd(dst + L.logprob, lps * kLn2);
                     unsafeAtomicAdd(dst + L.nobs, (double)__popcll(am & 0xFFFFull));
                 }
+            }
             }
             wave_sync();
         }
@@ -574,23 +599,24 @@ __global__ void fused_finish_kernel(const double* __restrict__ replicas, srx_mod
     }
 }
 
-template <int RQ, int H, int NTX>
+template <int RQ, int H, int NTX, bool POST = false>
 int launch(srx_context* h, const float* X, const int64_t* off, int64_t U, int64_t n_frames,
            const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* md,
            FusedTables tb, const int64_t* batch_base, float* lat, float* scale, double* replicas,
-           int rec_size, hipStream_t st) {
-    const size_t lds = sizeof(float) * 2 * (3 * 256 + 16 * frame_tile_stride(16 * RQ + 8 * H)) * kWavesPerBlock;
-    auto kern = estep_fused_kernel<RQ, H, NTX>;
+           int rec_size, hipStream_t st, float* post_out = nullptr, double* post_lp = nullptr) {
+    const size_t lds = POST ? 0 : sizeof(float) * 2 * (3 * 256 + 16 * frame_tile_stride(16 * RQ + 8 * H)) * kWavesPerBlock;
+    auto kern = estep_fused_kernel<RQ, H, NTX, POST>;
     SRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
     const int64_t n_groups = (U + 15) / 16;
     int64_t grid = (n_groups + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int64_t cap = (int64_t)h->n_cu * 2;
+    // (the posteriors variant needs fewer registers: three workgroups per CU)
+    const int64_t cap = (int64_t)h->n_cu * (POST ? 3 : 2);
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kWavesPerBlock), lds, st, X, off, U,
                        n_frames, utt_model, utt_order, md->n_models, md->n_states, md->n_features,
-                       tb, batch_base, lat, scale, replicas, rec_size);
+                       tb, batch_base, lat, scale, replicas, rec_size, post_out, post_lp);
     SRX_HIP(hipGetLastError());
     return SRX_OK;
 }
@@ -647,4 +673,102 @@ int srx_fused_estep(srx_context* h, const void* X, const int64_t* off, int64_t U
                        rec_size, out_stats);
     SRX_HIP(hipGetLastError());
     return SRX_OK;
+}
+
+// Processing order that groups the utterances of a model (any order inside a group:
+// an utterance's posteriors do not depend on its neighbours in the batch).
+// (counts and positions are taken in LDS first, one global atomic per model and
+// workgroup: 65,536 atomics on 6 addresses cost 0.2 ms per kernel otherwise)
+constexpr int kOrderModels = 4096;       // LDS histogram entries
+__global__ __launch_bounds__(256) void order_count_kernel(const int32_t* __restrict__ utt_model,
+                                                          int64_t U, int M,
+                                                          unsigned long long* __restrict__ cursor) {
+    __shared__ unsigned hist[kOrderModels];
+    for (int m = threadIdx.x; m < M; m += blockDim.x) hist[m] = 0u;
+    __syncthreads();
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < U) atomicAdd(&hist[utt_model[u]], 1u);
+    __syncthreads();
+    for (int m = threadIdx.x; m < M; m += blockDim.x)
+        if (hist[m]) atomicAdd(&cursor[m], (unsigned long long)hist[m]);
+}
+__global__ void order_scan_kernel(unsigned long long* cursor, int M) {
+    unsigned long long run = 0;
+    for (int m = 0; m < M; ++m) {
+        const unsigned long long c = cursor[m];
+        cursor[m] = run;
+        run += c;
+    }
+}
+__global__ __launch_bounds__(256) void order_scatter_kernel(const int32_t* __restrict__ utt_model,
+                                                            int64_t U, int M,
+                                                            unsigned long long* __restrict__ cursor,
+                                                            int64_t* __restrict__ order) {
+    __shared__ unsigned hist[kOrderModels];
+    __shared__ unsigned long long first[kOrderModels];
+    for (int m = threadIdx.x; m < M; m += blockDim.x) hist[m] = 0u;
+    __syncthreads();
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int m_u = u < U ? utt_model[u] : 0;
+    const unsigned rank = u < U ? atomicAdd(&hist[m_u], 1u) : 0u;
+    __syncthreads();
+    for (int m = threadIdx.x; m < M; m += blockDim.x)
+        if (hist[m]) first[m] = atomicAdd(&cursor[m], (unsigned long long)hist[m]);
+    __syncthreads();
+    if (u < U) order[first[m_u] + rank] = u;
+}
+
+// Posteriors of every frame under its utterance's model with the same kernel
+// (POST variant): out_post[frame][state] float32, out_lp[utterance] (0 for an empty one).
+int srx_fused_posteriors(srx_context* h, const void* X, const int64_t* off, int64_t U,
+                         int64_t n_frames, const int32_t* utt_model, const srx_models_t* md,
+                         float* out_post, double* out_lp, hipStream_t st) {
+    const int M = md->n_models, S = md->n_states, D = md->n_features;
+    if (S > 16 || D > 48 || n_frames <= 0 || U <= 0) return SRX_EUNSUPPORTED;
+    const int H = (D % 16 >= 1 && D % 16 <= 8) ? 1 : 0;
+    const int RQ = H ? D / 16 : (D + 15) / 16;
+    const int KW = 8 * RQ + 4 * H;
+    const size_t n_w = (size_t)M * 16 * KW * 4;
+    float* base;
+    int rc = srx_ws_ensure(h, WS_PARAMS,
+                           sizeof(float) * (n_w + (size_t)M * 16 * 2 + (size_t)M * 256),
+                           (void**)&base);
+    if (rc) return rc;
+    FusedTables tb;
+    float* cst = base + n_w;
+    float* A = cst + (size_t)M * 16;
+    float* pi = A + (size_t)M * 256;
+    tb.W = base; tb.cst = cst; tb.A = A; tb.pi = pi;
+    float *lat, *scale;
+    if ((rc = srx_ws_ensure(h, WS_LATTICE, sizeof(float) * (size_t)n_frames * 16, (void**)&lat))) return rc;
+    if ((rc = srx_ws_ensure(h, WS_SCALE, sizeof(float) * (size_t)n_frames, (void**)&scale))) return rc;
+    const int64_t n_batches = (U + 15) / 16;
+    int64_t* batch_base;
+    if ((rc = srx_ws_ensure(h, WS_MISC, sizeof(int64_t) * (size_t)n_batches, (void**)&batch_base))) return rc;
+    SRX_HIP(hipMemsetAsync(out_lp, 0, sizeof(double) * (size_t)U, st));
+    // a batch of 16 utterances is walked once per model present in it: group them
+    const int64_t* order = nullptr;
+    if (utt_model != nullptr && M > 1 && M <= kOrderModels) {
+        unsigned long long* cursor;
+        if ((rc = srx_ws_ensure(h, WS_BACKPTR, sizeof(int64_t) * ((size_t)U + (size_t)M), (void**)&cursor))) return rc;
+        int64_t* ord = (int64_t*)(cursor + M);
+        SRX_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned long long) * (size_t)M, st));
+        const unsigned gu = (unsigned)((U + 255) / 256);
+        hipLaunchKernelGGL(order_count_kernel, dim3(gu), dim3(256), 0, st, utt_model, U, M, cursor);
+        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1), 0, st, cursor, M);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3(gu), dim3(256), 0, st, utt_model, U, M, cursor, ord);
+        order = ord;
+    }
+    hipLaunchKernelGGL(fused_batch_total_kernel, dim3((unsigned)((n_batches + 255) / 256)), dim3(256),
+                       0, st, off, U, order, n_batches, batch_base);
+    hipLaunchKernelGGL(fused_batch_scan_kernel, dim3(1), dim3(1024), 0, st, n_batches, batch_base);
+    hipLaunchKernelGGL(fused_prep_kernel, dim3(24), dim3(256), 0, st, *md, RQ, H, base, cst, A, pi);
+    const float* Xf = (const float*)X;
+#define SRX_CASE(rq, hh)                                                                         \
+    if (RQ == rq && H == hh)                                                                     \
+        return launch<rq, hh, 1, true>(h, Xf, off, U, n_frames, utt_model, order, md, tb,        \
+                                       batch_base, lat, scale, nullptr, 0, st, out_post, out_lp);
+    SRX_CASE(0, 1) SRX_CASE(1, 0) SRX_CASE(1, 1) SRX_CASE(2, 0) SRX_CASE(2, 1) SRX_CASE(3, 0)
+#undef SRX_CASE
+    return SRX_EUNSUPPORTED;
 }

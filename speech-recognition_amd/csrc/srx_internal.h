@@ -137,6 +137,9 @@ int srx_large_viterbi_dense(srx_context* h, const void* ll, int dtype, const int
 int srx_fused_estep(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
                     const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* models,
                     double* out_stats, hipStream_t st);
+int srx_fused_posteriors(srx_context* h, const void* X, const int64_t* off, int64_t U,
+                         int64_t n_frames, const int32_t* utt_model, const srx_models_t* md,
+                         float* out_post, double* out_lp, hipStream_t st);
 
 // Implemented in mfcc_fast.hip (float32, nfft 512 / 1024), else SRX_EUNSUPPORTED.
 int srx_mfcc_fast_cepstra(srx_context* h, srx_mfcc_plan* plan, const float* audio,
