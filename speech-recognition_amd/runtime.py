@@ -177,6 +177,23 @@ class HMMBank:
             raise ValueError(
                 f"Unexpected number of dimensions, got {data.D} but expected {self.D}")
 
+    def _utt_model(self, data, utt_model):
+        """Model index per utterance as an int32 device tensor; host arrays are checked
+        (the kernels index their tables with these numbers), device tensors are taken
+        as they are."""
+        if utt_model is None:
+            return None
+        if isinstance(utt_model, torch.Tensor):
+            if utt_model.dtype != torch.int32 or utt_model.numel() != data.U:
+                raise ValueError("utt_model must be int32 with one entry per utterance")
+            return utt_model
+        um = np.asarray(utt_model, dtype=np.int32)
+        if um.shape != (data.U,):
+            raise ValueError("utt_model must have one entry per utterance")
+        if um.size and (um.min() < 0 or um.max() >= self.M):
+            raise ValueError("utt_model entry outside [0, n_models)")
+        return self.ctx.tensor(um)
+
     # -- kernels ---------------------------------------------------------
     def emission_loglik(self, data):
         self._check(data)
@@ -200,8 +217,7 @@ class HMMBank:
         self._check(data)
         path = torch.empty((data.n_frames,), dtype=torch.int32, device=self.ctx.device)
         lp = torch.empty((data.U,), dtype=torch.float64, device=self.ctx.device)
-        um = self.ctx.tensor(np.asarray(utt_model, dtype=np.int32)) if utt_model is not None and \
-            not isinstance(utt_model, torch.Tensor) else utt_model
+        um = self._utt_model(data, utt_model)
         check(lib.srx_viterbi(self.ctx.handle, ptr(data.X), data.code, ptr(data.offsets), data.U,
                               data.n_frames, ptr(um), C.byref(self._struct), ptr(path), ptr(lp),
                               self.ctx.stream_ptr()), "srx_viterbi")
@@ -214,8 +230,7 @@ class HMMBank:
         self._check(data)
         gamma = torch.empty((data.n_frames, self.S), dtype=data.X.dtype, device=self.ctx.device)
         lp = torch.empty((data.U,), dtype=torch.float64, device=self.ctx.device)
-        um = self.ctx.tensor(np.asarray(utt_model, dtype=np.int32)) if utt_model is not None and \
-            not isinstance(utt_model, torch.Tensor) else utt_model
+        um = self._utt_model(data, utt_model)
         check(lib.srx_posteriors(self.ctx.handle, ptr(data.X), data.code, ptr(data.offsets), data.U,
                                  data.n_frames, ptr(um), C.byref(self._struct), ptr(gamma), ptr(lp),
                                  self.ctx.stream_ptr()), "srx_posteriors")
@@ -227,6 +242,7 @@ class HMMBank:
         if out is None:
             out = torch.empty((self.M, self.stats_size), dtype=torch.float64, device=self.ctx.device)
         fn = lib.srx_estep_stats_generic if generic else lib.srx_estep_stats
+        utt_model = self._utt_model(data, utt_model)
         check(fn(self.ctx.handle, ptr(data.X), data.code, ptr(data.offsets), data.U,
                                   data.n_frames, ptr(utt_model), ptr(utt_order),
                                   C.byref(self._struct), ptr(out), self.ctx.stream_ptr()),
