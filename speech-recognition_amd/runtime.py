@@ -372,12 +372,25 @@ class MfccPlan:
             out = torch.empty((int(fo[-1]), self.n_feat), dtype=tdt, device=self.ctx.device)
         if fo[-1] == 0:
             return out, fo
-        so_d, fo_d = self.ctx.tensor(so), self.ctx.tensor(fo)
-        check(lib.srx_mfcc_batch(self.ctx.handle, self._p, ptr(a), code, ptr(so_d), len(lens),
-                                 int(so[-1]), ptr(out), ptr(fo_d), self.ctx.stream_ptr()),
-              "srx_mfcc_batch")
-        # the offset tensors must outlive the asynchronous kernels
-        self._keep = (a, so_d, fo_d)
+        # The fast kernels address one call's samples with 31 bits: longer buffers go in
+        # slices of whole utterances (an utterance that is itself longer runs alone,
+        # through the generic kernels).
+        limit = (1 << 31) - 512
+        self._keep = [a]
+        u0 = 0
+        while u0 < len(lens):
+            u1 = int(np.searchsorted(so, so[u0] + limit, side="right")) - 1
+            u1 = max(u1, u0 + 1)
+            so_d = self.ctx.tensor(so[u0:u1 + 1] - so[u0])
+            fo_d = self.ctx.tensor(fo[u0:u1 + 1] - fo[u0])
+            if fo[u1] > fo[u0]:
+                check(lib.srx_mfcc_batch(self.ctx.handle, self._p, ptr(a[so[u0]:so[u1]]), code,
+                                         ptr(so_d), u1 - u0, int(so[u1] - so[u0]),
+                                         ptr(out[fo[u0]:fo[u1]]), ptr(fo_d), self.ctx.stream_ptr()),
+                      "srx_mfcc_batch")
+            # the offset tensors must outlive the asynchronous kernels
+            self._keep += [so_d, fo_d]
+            u0 = u1
         return out, fo
 
     def close(self):

@@ -230,6 +230,30 @@ def test_endpoint_full_size_properties(sra, ctx):
         assert torch.equal(one.segments[0], res.segments[r])
 
 
+def test_front_end_beyond_2g_samples(sra, ctx):
+    """46,000 recordings x 3 s = 2.2e9 samples in one call (more than the fast kernels
+    address at once: the host layer cuts the call into slices of whole utterances):
+    recordings either side of the cut give the features they give on their own."""
+    import torch
+    R, n = 46000, 48000
+    audio = torch.empty((R * n,), device="cuda", dtype=torch.float32)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(23)
+    step = 1 << 26
+    for i in range(0, R * n, step):
+        audio[i:i + step].normal_(generator=g)
+    audio *= 0.1
+    so = np.arange(0, (R + 1) * n, n, dtype=np.int64)
+    plan = sra.MfccPlan(ctx, 16000, nfft=512, n_mel=40, delta_order=2, zscore=True)
+    feats, fo = plan.run(audio, so)
+    assert feats.shape == (R * 294, 39) and bool(torch.isfinite(feats[::1000]).all())
+    cut = int(np.searchsorted(so, (1 << 31) - 512, side="right")) - 1      # first recording of slice 2
+    for r in (0, cut - 1, cut, R - 1):
+        one, _ = plan.run(audio[r * n:(r + 1) * n], [0, n])
+        assert torch.equal(one, feats[fo[r]:fo[r + 1]])
+    del feats, audio
+
+
 def test_addressing_beyond_4gib(sra, ctx):
     """262,144 utterances x 200 x 39 floats = 7.6 GiB of features: results for
     utterances past the 4 GiB mark equal those of the same data processed on its own
