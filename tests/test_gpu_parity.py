@@ -595,3 +595,22 @@ def test_hmmlearn_style_class(sra, ctx):
     post = m.predict_proba(X, lengths)
     np.testing.assert_array_equal(path_m, post.argmax(axis=1))
     assert np.mean(path_v == path_m) > 0.95
+
+
+def test_empty_inputs_of_the_added_entry_points(sra, ctx):
+    """No recordings / no utterances / only empty ones: nothing is launched out of range,
+    shapes come back empty."""
+    res = sra.endpoint.detect_batch(np.zeros(0, dtype=np.float32), [0], 16000, ctx=ctx)
+    assert res.counts.numel() == 0 and res.energy.numel() == 0
+    res = sra.endpoint.detect_batch(np.zeros(0, dtype=np.float32), [0, 0, 0], 16000, ctx=ctx)
+    assert res.counts.cpu().tolist() == [0, 0] and res.segments_host() == [[], []]
+    packed, new_so, _ = sra.endpoint.cut_batch(np.zeros(100, dtype=np.float32), [0, 100], 16000, ctx=ctx)
+    assert packed.numel() == 0 and new_so.tolist() == [0, 0]
+    rng = np.random.default_rng(0)
+    bank = _bank(sra, ctx, [ho.random_params(rng, 5, 7)])
+    for dtype in ("float32", "float64"):
+        lp, gam = bank.posteriors(sra.Ragged(ctx, np.zeros((0, 7)), [0, 0, 0], dtype=dtype))
+        assert gam.shape == (0, 5) and lp.cpu().tolist() == [0.0, 0.0, 0.0]
+        lp, gam = bank.posteriors(sra.Ragged(ctx, rng.standard_normal((3, 7)), [0, 3, 0], dtype=dtype))
+        assert gam.shape == (3, 5) and lp[0] == 0 and lp[2] == 0 and float(lp[1]) < 0
+        np.testing.assert_allclose(gam.sum(dim=1).cpu().numpy(), 1.0, atol=1e-5)
