@@ -442,6 +442,105 @@ __global__ void viterbi_chain_kernel(const T* __restrict__ loglik,
     }
 }
 
+// Viterbi for models of at most 8 states, float32: ONE LANE per utterance.  The lane
+// keeps log A (S x S) and delta (S) in registers, so a step is S^2 add / compare /
+// select triples without any cross-lane traffic; log-densities are read four frames
+// at a time (one 4 S-float piece), the S back-pointers of a frame are packed into one
+// word (3 bits each), written four frames at a time, and the backtrace resolves four
+// frames per load instead of one dependent byte load per frame.  Ties take the lowest
+// state, as np.argmax does (utils.py:243-266).
+template <int S>
+__global__ __launch_bounds__(64) void viterbi_lane_kernel(
+    const float* __restrict__ loglik, const int64_t* __restrict__ off, int64_t U,
+    const int32_t* __restrict__ utt_model, Tables<float> tb, uint32_t* __restrict__ bpw,
+    int32_t* __restrict__ path, double* __restrict__ out_lp) {
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const int m = utt_model ? utt_model[u] : 0;
+    const int64_t f0 = off[u];
+    const int T_len = (int)(off[u + 1] - f0);
+    if (T_len <= 0) {
+        out_lp[u] = 0.0;
+        return;
+    }
+    struct __attribute__((packed, aligned(4))) Rows4 { float v[4 * S]; };   // rows are 4-byte aligned
+    struct __attribute__((packed, aligned(4))) Words4 { uint32_t v[4]; };
+    float la[S][S], d[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i)
+#pragma unroll
+        for (int j = 0; j < S; ++j) la[i][j] = tb.logA[((size_t)m * S + i) * S + j];
+    const float* ll = loglik + f0 * S;
+    uint32_t* bw = bpw + f0;
+#pragma unroll
+    for (int j = 0; j < S; ++j) d[j] = tb.logpi[m * S + j] + ll[j];
+    auto step = [&](const float* row) {
+        float nd[S];
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            float best = neg_inf<float>();
+            uint32_t arg = 0;
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                const float cand = d[i] + la[i][j];
+                arg = cand > best ? (uint32_t)i : arg;       // strict: the lowest index wins ties
+                best = cand > best ? cand : best;
+            }
+            nd[j] = best + row[j];
+            word |= arg << (3 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < S; ++j) d[j] = nd[j];
+        return word;
+    };
+    // frames 1 .. T-1 in pieces of four, the next piece requested before this one is used
+    int t = 1;
+    Rows4 cur, nxt;
+    if (t + 4 <= T_len) cur = *(const Rows4*)(ll + (size_t)t * S);
+    for (; t + 4 <= T_len; t += 4) {
+        if (t + 8 <= T_len) nxt = *(const Rows4*)(ll + (size_t)(t + 4) * S);
+        Words4 w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w.v[k] = step(cur.v + k * S);
+        *(Words4*)(bw + t) = w;
+        cur = nxt;
+    }
+    for (; t < T_len; ++t) {
+        float row[S];
+#pragma unroll
+        for (int j = 0; j < S; ++j) row[j] = ll[(size_t)t * S + j];
+        bw[t] = step(row);
+    }
+    float best = neg_inf<float>();
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < S; ++i)
+        if (d[i] > best) {
+            best = d[i];
+            s = i;
+        }
+    out_lp[u] = (double)best;
+    // backtrace: path[t] = back-pointer of frame t+1 at the state of frame t+1
+    int32_t* p = path + f0;
+    p[T_len - 1] = s;
+    t = T_len - 1;                       // frame whose word is looked up next
+    for (; t >= 4; t -= 4) {
+        const Words4 w = *(const Words4*)(bw + t - 3);       // words of frames t-3 .. t
+        Words4 o;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+            s = (int)((w.v[k] >> (3 * s)) & 7u);
+            o.v[k] = (uint32_t)s;                             // state of frame t-4+k
+        }
+        *(Words4*)(p + t - 4) = o;
+    }
+    for (; t >= 1; --t) {
+        s = (int)((bw[t] >> (3 * s)) & 7u);
+        p[t - 1] = s;
+    }
+}
+
 // One workgroup per model.
 __global__ void mstep_kernel(const double* __restrict__ stats, srx_priors_t pr, int mode,
                              srx_models_t md) {
@@ -598,6 +697,24 @@ int viterbi_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int6
     if (!done)
         hipLaunchKernelGGL(emission_kernel<T>, dim3(grid_for(h, U, 1)), dim3(kBlock), 0, st,
                            (const T*)X, off, U, utt_model, 0, M, S, D, tb, ll);
+    if constexpr (std::is_same<T, float>::value) {
+        if (S <= 8) {
+            // (the back-pointer buffer holds one packed word per frame here)
+            uint32_t* bpw;
+            rc = srx_ws_ensure(h, WS_BACKPTR, sizeof(uint32_t) * (size_t)n_frames, (void**)&bpw);
+            if (rc) return rc;
+            const dim3 grid((unsigned)((U + 63) / 64));
+#define SRX_CASE(s_)                                                                          \
+    if (S == s_)                                                                              \
+        hipLaunchKernelGGL((viterbi_lane_kernel<s_>), grid, dim3(64), 0, st, (const float*)ll, \
+                           off, U, utt_model, tb, bpw, path, lp);
+            SRX_CASE(1) SRX_CASE(2) SRX_CASE(3) SRX_CASE(4) SRX_CASE(5) SRX_CASE(6) SRX_CASE(7)
+            SRX_CASE(8)
+#undef SRX_CASE
+            SRX_HIP(hipGetLastError());
+            return SRX_OK;
+        }
+    }
     const int sp = sub_width(S);
     SP_DISPATCH(sp, hipLaunchKernelGGL((viterbi_chain_kernel<T, SP>),
                                        dim3(grid_for(h, U, kBlock / SP)), dim3(kBlock), 0, st,
