@@ -19,8 +19,8 @@
 //      plan: weights per (quad, lane), first bin per block).  Blocks that share
 //      filters add up through LDS; log10; the DCT's 16 blocks are 4 groups of
 //      cepstra x 4 slices of the filters, added across lanes at the end.
-// A wave carries 4 frames at once, a workgroup 16; work items are cut from the
-// packed sample axis exactly as in the generic kernel (mfcc.hip).
+// A wave carries 4 frames at once, a workgroup 16 (12 in the 1024-point kernel); work
+// items are cut from the packed sample axis exactly as in the generic kernel (mfcc.hip).
 #include "srx_internal.h"
 
 #include <math.h>
@@ -28,7 +28,9 @@
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kFramesPerBlock = 16;
+// Frames a workgroup transforms at once (4 per wave).  The 1024-point kernel takes 12:
+// two workgroups of it fit the LDS of a CU, one of 16 frames would be alone.
+template <int P> constexpr int frames_per_block() { return P == 16 ? 16 : 12; }
 
 struct FastDev {
     int frame_len, hop, n_used, n_mel, n_ceps, nnz;
@@ -117,7 +119,7 @@ __device__ __forceinline__ int64_t raw_frames(int64_t n, int L, int hop) {
 }
 
 template <int P>
-__global__ __launch_bounds__(256, P == 16 ? 3 : 1) void cepstra_fast_kernel(
+__global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_fast_kernel(
     const float* __restrict__ audio, const int64_t* __restrict__ so, int64_t U, int64_t total,
     FastDev c, float* __restrict__ cep) {
     constexpr int H = 16 * P, N = 2 * H, KB = P / 16;   // KB 16-point FFTs per lane in step 3
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256, P == 16 ? 3 : 1) void cepstra_fast_kernel(
     // position then advances monotonically (offsets cached in registers, no search
     // per chunk), and the samples of chunk b+1 are requested before chunk b is
     // transformed, so neither the offset lookups nor the sample loads stall it.
-    const int64_t chunk = (int64_t)kFramesPerBlock * c.hop;
+    const int64_t chunk = (int64_t)frames_per_block<P>() * c.hop;
     const int64_t n_chunks = (total + chunk - 1) / chunk;
     const int64_t per_block = (n_chunks + gridDim.x - 1) / gridDim.x;
     const int64_t b_begin = (int64_t)blockIdx.x * per_block;
@@ -415,21 +417,21 @@ int launch_fast(srx_context* h, const float* audio, const int64_t* so, int64_t U
                           4 * ((size_t)N + (size_t)d.nq * 256 + 64 * (size_t)d.kk + 48);
     const size_t per_frame = 4 * (size_t)2 * YS;
     if ((size_t)(H + 4) + 4 * (size_t)d.kk + 64 > (size_t)2 * YS) return SRX_EUNSUPPORTED;
-    const size_t lds = tables + per_frame * kFramesPerBlock;
+    const size_t lds = tables + per_frame * frames_per_block<P>();
 
     if (lds > 160 * 1024) return SRX_EUNSUPPORTED;
     auto kern = cepstra_fast_kernel<P>;
     SRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t chunk = (int64_t)kFramesPerBlock * d.hop;
+    const int64_t chunk = (int64_t)frames_per_block<P>() * d.hop;
     const int64_t n_chunks = (total + chunk - 1) / chunk;
     // four rounds of the workgroups that fit a CU at once (LDS decides)
     int per_cu = (int)((160 * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
-    if (P != 16) per_cu = 1;
+    if (P != 16 && per_cu > 2) per_cu = 2;
     const int64_t want = (int64_t)h->n_cu * per_cu * 4;
     int64_t grid = n_chunks < want ? n_chunks : want;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, audio, so, U, total, d, cep);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(16 * frames_per_block<P>()), lds, st, audio, so, U, total, d, cep);
     SRX_HIP(hipGetLastError());
     return SRX_OK;
 }

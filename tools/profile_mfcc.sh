@@ -4,7 +4,7 @@ set -e
 ROOT=$(pwd)
 TAG=${1:-mfcc}
 cd /tmp && export TMPDIR=/tmp
-rm -rf $ROOT/gpurun_out/$TAG; timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/$TAG -- python $ROOT/tools/mfcc_bench.py $2 $3 > /dev/null 2>&1
+rm -rf $ROOT/gpurun_out/$TAG; timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/$TAG -- python $ROOT/tools/mfcc_bench.py $2 $3 $4 > /dev/null 2>&1
 f=$(find $ROOT/gpurun_out/$TAG -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
