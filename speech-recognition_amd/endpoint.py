@@ -111,6 +111,40 @@ def cut_batch(audio, sample_offsets, fs, *, dtype="float32", ctx=None, **kw):
     return packed, np.asarray(new_so, dtype=np.int64), res
 
 
+def clean_recordings(signals, fs, *, chunk_seconds=1, dtype="float32", ctx=None, to_host=True, **kw):
+    """The offline cleaning pass of the reference for many recordings at once
+    (process_recorded_audio / process_chunk / get_cleaned_audio,
+    new_speech_detect.py:509-517, :555-606): every recording is cut into chunks of
+    ``chunk_seconds``, each chunk is end-pointed on its own, and the speech pieces of
+    a recording's chunks are concatenated.  All chunks of all recordings go through
+    one srx_endpoint_detect launch.  Returns the cleaned recordings (numpy arrays,
+    or device tensors with ``to_host=False``); a recording without speech comes back
+    empty."""
+    ctx = ctx or Context.default()
+    tdt, _, _ = dtype_info(dtype)
+    chunk = int(fs * chunk_seconds)
+    lens = np.array([len(s) for s in signals], dtype=np.int64)
+    npdt = np.float64 if dtype == "float64" else np.float32
+    packed = np.concatenate([np.asarray(s, dtype=npdt).reshape(-1) for s in signals]) \
+        if len(signals) else np.zeros(0, dtype=npdt)
+    # chunk boundaries inside every recording
+    bounds, owner = [0], []
+    base = 0
+    for r, n in enumerate(lens):
+        for a in range(0, int(n), chunk):
+            bounds.append(base + min(a + chunk, int(n)))
+            owner.append(r)
+        base += int(n)
+    cut, new_so, _ = cut_batch(packed, np.asarray(bounds, dtype=np.int64), fs, dtype=dtype, ctx=ctx, **kw)
+    out = []
+    owner = np.asarray(owner, dtype=np.int64)
+    for r in range(len(signals)):
+        idx = np.nonzero(owner == r)[0]
+        piece = cut[new_so[idx[0]]:new_so[idx[-1] + 1]] if len(idx) else cut[:0]
+        out.append(piece.cpu().numpy() if to_host else piece)
+    return out
+
+
 class AudioMonitor:
     """The reference's class for saved audio (new_speech_detect.py:30-43, :320-334,
     :447-470).  ``device`` is accepted for signature compatibility."""

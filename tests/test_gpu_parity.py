@@ -614,3 +614,19 @@ def test_empty_inputs_of_the_added_entry_points(sra, ctx):
         lp, gam = bank.posteriors(sra.Ragged(ctx, rng.standard_normal((3, 7)), [0, 3, 0], dtype=dtype))
         assert gam.shape == (3, 5) and lp[0] == 0 and lp[2] == 0 and float(lp[1]) < 0
         np.testing.assert_allclose(gam.sum(dim=1).cpu().numpy(), 1.0, atol=1e-5)
+
+
+def test_clean_recordings_matches_reference_chunks(sra, ctx, endpoint_golden):
+    """The two raw recordings of the fixtures (three 1 s chunks each), cleaned in one
+    batch: equal to the reference's per-chunk cuts put end to end."""
+    g = endpoint_golden
+    n = int(g["n"])
+    recs = [[n - 6, n - 5, n - 4], [n - 3, n - 2, n - 1]]          # chunk indices per recording
+    signals = [np.concatenate([g[f"x{i}"] for i in idx]) for idx in recs]
+    assert all(len(s) == 66150 for s in signals)
+    for dtype in ("float32", "float64"):
+        got = sra.endpoint.clean_recordings(signals, 22050, dtype=dtype, ctx=ctx)
+        for idx, out in zip(recs, got):
+            want = np.concatenate([g[f"cut{i}"] for i in idx])
+            np.testing.assert_array_equal(out.astype(np.float32), want)
+    assert sra.endpoint.clean_recordings([], 22050, ctx=ctx) == []
