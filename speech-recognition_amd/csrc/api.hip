@@ -193,7 +193,9 @@ int srx_posteriors(srx_handle_t h, const void* X, int dtype, const int64_t* utt_
     SRX_REQUIRE(out_logprob != nullptr && (n_frames == 0 || out_posteriors != nullptr),
                 "srx_posteriors: NULL output");
     SRX_HIP(hipSetDevice(h->device));
-    if (dtype == SRX_F32 && n_frames > 0) {
+    // (models of at most 8 states: the lane-per-utterance kernel behind
+    // srx_generic_posteriors is the faster one)
+    if (dtype == SRX_F32 && n_frames > 0 && models->n_states > 8) {
         rc = srx_fused_posteriors(h, X, utt_offsets, n_utts, n_frames, utt_model, models,
                                   (float*)out_posteriors, out_logprob, (hipStream_t)stream);
         if (rc != SRX_EUNSUPPORTED) return rc;

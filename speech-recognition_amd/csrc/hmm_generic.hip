@@ -541,6 +541,184 @@ __global__ __launch_bounds__(64) void viterbi_lane_kernel(
     }
 }
 
+// Posteriors for models of at most 8 states, float32: ONE LANE per utterance, like
+// viterbi_lane_kernel.  The transition matrix (both orientations of its use come from
+// the same S x S registers), the scaled forward vector and b~ beta stay in registers;
+// log-densities, the lattice (kept in the output array until the backward pass
+// replaces it by the posteriors) and the scale factors move four frames at a time.
+// The arithmetic is fb_chain_kernel's: b~ = exp(l - max l), alpha scaled to sum 1,
+// beta with the same factors, gamma = alpha beta normalised (zero rows divide by 1).
+template <int S>
+__global__ __launch_bounds__(64) void fb_lane_kernel(
+    const float* __restrict__ loglik, const int64_t* __restrict__ off, int64_t U,
+    const int32_t* __restrict__ utt_model, Tables<float> tb, float* __restrict__ lat,
+    float* __restrict__ scale, double* __restrict__ utt_lp) {
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const int m = utt_model ? utt_model[u] : 0;
+    const int64_t f0 = off[u];
+    const int T_len = (int)(off[u + 1] - f0);
+    if (T_len <= 0) {
+        utt_lp[u] = 0.0;
+        return;
+    }
+    struct __attribute__((packed, aligned(4))) Rows4 { float v[4 * S]; };   // rows are 4-byte aligned
+    struct __attribute__((packed, aligned(4))) Four { float v[4]; };
+    float A[S][S];
+#pragma unroll
+    for (int i = 0; i < S; ++i)
+#pragma unroll
+        for (int j = 0; j < S; ++j) A[i][j] = tb.A[((size_t)m * S + i) * S + j];
+    const float* ll = loglik + f0 * S;
+    float* la = lat + f0 * S;
+    float* sc = scale + f0;
+    // b~ of one frame (and the row maximum it was shifted by)
+    auto emis = [&](const float* row, float (&b)[S]) {
+        float mx = row[0];
+#pragma unroll
+        for (int j = 1; j < S; ++j) mx = fmaxf(mx, row[j]);
+#pragma unroll
+        for (int j = 0; j < S; ++j) b[j] = __expf(row[j] - mx);      // (hardware exp2: ~1 ulp)
+        return mx;
+    };
+    // ---- forward
+    float alpha[S];
+    double lp = 0.0;
+    float lpf = 0.f;              // float partial sum of the log-probability, folded every 4 frames
+    auto fwd = [&](bool first, const float* row, float* out_row) {
+        float b[S], a[S];
+        const float mx = emis(row, b);
+        if (first) {
+#pragma unroll
+            for (int j = 0; j < S; ++j) a[j] = tb.pi[m * S + j] * b[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < S; ++i) acc += alpha[i] * A[i][j];
+                a[j] = acc * b[j];
+            }
+        }
+        float c = 0.f;
+#pragma unroll
+        for (int j = 0; j < S; ++j) c += a[j];
+        lpf += mx + __logf(c);
+        const float ci = __builtin_amdgcn_rcpf(c);
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            alpha[j] = a[j] * ci;
+            out_row[j] = alpha[j];
+        }
+        return ci;
+    };
+    {
+        float row[S], o[S];
+#pragma unroll
+        for (int j = 0; j < S; ++j) row[j] = ll[j];
+        sc[0] = fwd(true, row, o);
+#pragma unroll
+        for (int j = 0; j < S; ++j) la[j] = o[j];
+    }
+    int t = 1;
+    Rows4 cur, nxt;
+    if (t + 4 <= T_len) cur = *(const Rows4*)(ll + (size_t)t * S);
+    for (; t + 4 <= T_len; t += 4) {
+        if (t + 8 <= T_len) nxt = *(const Rows4*)(ll + (size_t)(t + 4) * S);
+        Rows4 o;
+        Four c4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c4.v[k] = fwd(false, cur.v + k * S, o.v + k * S);
+        *(Rows4*)(la + (size_t)t * S) = o;
+        *(Four*)(sc + t) = c4;
+        cur = nxt;
+        lp += (double)lpf;
+        lpf = 0.f;
+    }
+    for (; t < T_len; ++t) {
+        float row[S], o[S];
+#pragma unroll
+        for (int j = 0; j < S; ++j) row[j] = ll[(size_t)t * S + j];
+        sc[t] = fwd(false, row, o);
+#pragma unroll
+        for (int j = 0; j < S; ++j) la[(size_t)t * S + j] = o[j];
+    }
+    utt_lp[u] = lp + (double)lpf;
+    // ---- backward: frames T-1 .. 0; bb = b~_{t+1} beta_{t+1}
+    float bb[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) bb[j] = 0.f;
+    auto bwd = [&](bool last, const float* row, const float* arow, float ci, float* out_row) {
+        float beta[S];
+        if (last) {
+#pragma unroll
+            for (int i = 0; i < S; ++i) beta[i] = ci;
+        } else {
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < S; ++j) acc += A[i][j] * bb[j];
+                beta[i] = acc * ci;
+            }
+        }
+        float g[S], gs = 0.f;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            g[i] = arow[i] * beta[i];
+            gs += g[i];
+        }
+        if (gs == 0.f) gs = 1.f;                 // utils.normalize: zero rows divide by 1
+        const float gi = __builtin_amdgcn_rcpf(gs);
+        float b[S];
+        emis(row, b);
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            out_row[i] = g[i] * gi;
+            bb[i] = b[i] * beta[i];
+        }
+    };
+    t = T_len - 1;
+    bool last = true;
+    // (the piece below the current one is requested before the current one is used)
+    Rows4 lr, ar, lr_n, ar_n;
+    Four c4, c4_n;
+    if (t >= 3) {
+        lr = *(const Rows4*)(ll + (size_t)(t - 3) * S);
+        ar = *(const Rows4*)(la + (size_t)(t - 3) * S);
+        c4 = *(const Four*)(sc + t - 3);
+    }
+    for (; t >= 3; t -= 4) {
+        if (t >= 7) {
+            lr_n = *(const Rows4*)(ll + (size_t)(t - 7) * S);
+            ar_n = *(const Rows4*)(la + (size_t)(t - 7) * S);
+            c4_n = *(const Four*)(sc + t - 7);
+        }
+        Rows4 o;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+            bwd(last, lr.v + k * S, ar.v + k * S, c4.v[k], o.v + k * S);
+            last = false;
+        }
+        *(Rows4*)(la + (size_t)(t - 3) * S) = o;
+        lr = lr_n;
+        ar = ar_n;
+        c4 = c4_n;
+    }
+    for (; t >= 0; --t) {
+        float row[S], ar[S], o[S];
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            row[j] = ll[(size_t)t * S + j];
+            ar[j] = la[(size_t)t * S + j];
+        }
+        bwd(last, row, ar, sc[t], o);
+        last = false;
+#pragma unroll
+        for (int j = 0; j < S; ++j) la[(size_t)t * S + j] = o[j];
+    }
+}
+
 // One workgroup per model.
 __global__ void mstep_kernel(const double* __restrict__ stats, srx_priors_t pr, int mode,
                              srx_models_t md) {
@@ -749,6 +927,21 @@ int posteriors_t(srx_context* h, const void* X, const int64_t* off, int64_t U, i
     if (!done)
         hipLaunchKernelGGL(emission_kernel<T>, dim3(grid_for(h, U, 1)), dim3(kBlock), 0, st,
                            (const T*)X, off, U, utt_model, 0, M, S, D, tb, ll);
+    if constexpr (std::is_same<T, float>::value) {
+        if (S <= 8) {
+            const int bs = 64;
+            const dim3 grid((unsigned)((U + bs - 1) / bs));
+#define SRX_CASE(s_)                                                                       \
+    if (S == s_)                                                                           \
+        hipLaunchKernelGGL((fb_lane_kernel<s_>), grid, dim3(bs), 0, st, (const float*)ll,  \
+                           off, U, utt_model, tb, (float*)gamma, (float*)sc, lp);
+            SRX_CASE(1) SRX_CASE(2) SRX_CASE(3) SRX_CASE(4) SRX_CASE(5) SRX_CASE(6) SRX_CASE(7)
+            SRX_CASE(8)
+#undef SRX_CASE
+            SRX_HIP(hipGetLastError());
+            return SRX_OK;
+        }
+    }
     const int sp = sub_width(S);
     SP_DISPATCH(sp, hipLaunchKernelGGL((fb_chain_kernel<T, SP>),
                                        dim3(grid_for(h, U, kBlock / SP)), dim3(kBlock), 0, st,
