@@ -208,8 +208,10 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
 
     for (int64_t k = k0; k < k1; ++k) {
         const int64_t e = k * 16 + ul;
-        const bool valid = e < U;
-        const int64_t u = valid ? (utt_order ? utt_order[e] : e) : 0;
+        // (U counts the entries of the visiting order here; a negative entry is an empty lane)
+        const int64_t u_raw = e < U ? (utt_order ? utt_order[e] : e) : -1;
+        const bool valid = u_raw >= 0;
+        const int64_t u = valid ? u_raw : 0;
         const int m_l = valid ? (utt_model ? utt_model[u] : 0) : -1;
         const int64_t f_start = valid ? off[u] : 0;
         const int T_l = valid ? (int)(off[u + 1] - f_start) : 0;
@@ -553,7 +555,7 @@ __global__ void fused_batch_total_kernel(const int64_t* __restrict__ off, int64_
         const int64_t e = b * 16 + j;
         if (e < U) {
             const int64_t u = utt_order ? utt_order[e] : e;
-            sum += off[u + 1] - off[u];
+            if (u >= 0) sum += off[u + 1] - off[u];
         }
     }
     base[b] = sum;
@@ -623,6 +625,76 @@ int launch(srx_context* h, const float* X, const int64_t* off, int64_t U, int64_
 
 }  // namespace
 
+// Processing order that groups the utterances of a model (any order inside a group:
+// an utterance's posteriors do not depend on its neighbours in the batch).
+// (counts and positions are taken in LDS first, one global atomic per model and
+// workgroup: 65,536 atomics on 6 addresses cost 0.2 ms per kernel otherwise)
+constexpr int kOrderModels = 4096;       // LDS histogram entries
+__global__ __launch_bounds__(256) void order_count_kernel(const int32_t* __restrict__ utt_model,
+                                                          int64_t U, int M,
+                                                          unsigned long long* __restrict__ cursor) {
+    __shared__ unsigned hist[kOrderModels];
+    for (int m = threadIdx.x; m < M; m += blockDim.x) hist[m] = 0u;
+    __syncthreads();
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < U) atomicAdd(&hist[utt_model[u]], 1u);
+    __syncthreads();
+    for (int m = threadIdx.x; m < M; m += blockDim.x)
+        if (hist[m]) atomicAdd(&cursor[m], (unsigned long long)hist[m]);
+}
+// (every model's group starts at a multiple of 16 entries, so that no batch of 16 mixes
+// models; the gaps stay -1 = empty lanes)
+__global__ void order_scan_kernel(unsigned long long* cursor, int M) {
+    unsigned long long run = 0;
+    for (int m = 0; m < M; ++m) {
+        const unsigned long long c = cursor[m];
+        cursor[m] = run;
+        run += (c + 15ull) & ~15ull;
+    }
+}
+__global__ __launch_bounds__(256) void order_scatter_kernel(const int32_t* __restrict__ utt_model,
+                                                            int64_t U, int M,
+                                                            unsigned long long* __restrict__ cursor,
+                                                            int64_t* __restrict__ order) {
+    __shared__ unsigned hist[kOrderModels];
+    __shared__ unsigned long long first[kOrderModels];
+    for (int m = threadIdx.x; m < M; m += blockDim.x) hist[m] = 0u;
+    __syncthreads();
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int m_u = u < U ? utt_model[u] : 0;
+    const unsigned rank = u < U ? atomicAdd(&hist[m_u], 1u) : 0u;
+    __syncthreads();
+    for (int m = threadIdx.x; m < M; m += blockDim.x)
+        if (hist[m]) first[m] = atomicAdd(&cursor[m], (unsigned long long)hist[m]);
+    __syncthreads();
+    if (u < U) order[first[m_u] + rank] = u;
+}
+
+// Builds that order in the context's back-pointer scratch (not otherwise used by the
+// callers below); *order stays NULL when there is nothing to group.  *entries is the
+// length of the order: U, or an upper bound of the padded length (the host does not
+// know the group sizes; what lies behind the last group is empty lanes).
+static int build_model_order(srx_context* h, const int32_t* utt_model, int64_t U, int M,
+                             hipStream_t st, const int64_t** order, int64_t* entries) {
+    *order = nullptr;
+    *entries = U;
+    if (utt_model == nullptr || M <= 1 || M > kOrderModels) return SRX_OK;
+    const int64_t E = (U + 15 * (int64_t)M + 15) / 16 * 16;
+    unsigned long long* cursor;
+    int rc = srx_ws_ensure(h, WS_BACKPTR, sizeof(int64_t) * ((size_t)E + (size_t)M), (void**)&cursor);
+    if (rc) return rc;
+    int64_t* ord = (int64_t*)(cursor + M);
+    SRX_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned long long) * (size_t)M, st));
+    SRX_HIP(hipMemsetAsync(ord, 0xFF, sizeof(int64_t) * (size_t)E, st));
+    const unsigned gu = (unsigned)((U + 255) / 256);
+    hipLaunchKernelGGL(order_count_kernel, dim3(gu), dim3(256), 0, st, utt_model, U, M, cursor);
+    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1), 0, st, cursor, M);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(gu), dim3(256), 0, st, utt_model, U, M, cursor, ord);
+    *order = ord;
+    *entries = E;
+    return SRX_OK;
+}
+
 int srx_fused_estep(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
                     const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* md,
                     double* out_stats, hipStream_t st) {
@@ -651,17 +723,21 @@ int srx_fused_estep(srx_context* h, const void* X, const int64_t* off, int64_t U
     const size_t rep_bytes = sizeof(double) * (size_t)kReplicas * M * rec_size;
     if ((rc = srx_ws_ensure(h, WS_PARTIAL, rep_bytes, (void**)&replicas))) return rc;
     SRX_HIP(hipMemsetAsync(replicas, 0, rep_bytes, st));
-    const int64_t n_batches = (U + 15) / 16;
+    // (a caller that gives no visiting order gets one that groups the utterances by
+    // model: a batch of 16 is walked once per model present in it)
+    int64_t E = U;                      // entries of the visiting order
+    if (utt_order == nullptr && (rc = build_model_order(h, utt_model, U, M, st, &utt_order, &E))) return rc;
+    const int64_t n_batches = (E + 15) / 16;
     int64_t* batch_base;
     if ((rc = srx_ws_ensure(h, WS_MISC, sizeof(int64_t) * (size_t)n_batches, (void**)&batch_base))) return rc;
     hipLaunchKernelGGL(fused_batch_total_kernel, dim3((unsigned)((n_batches + 255) / 256)), dim3(256),
-                       0, st, off, U, utt_order, n_batches, batch_base);
+                       0, st, off, E, utt_order, n_batches, batch_base);
     hipLaunchKernelGGL(fused_batch_scan_kernel, dim3(1), dim3(1024), 0, st, n_batches, batch_base);
     hipLaunchKernelGGL(fused_prep_kernel, dim3(24), dim3(256), 0, st, *md, RQ, H, base, cst, A, pi);
     const float* Xf = (const float*)X;
 #define SRX_CASE(rq, hh, ntx)                                                                \
     if (RQ == rq && H == hh && NTX == ntx) {                                                  \
-        rc = launch<rq, hh, ntx>(h, Xf, off, U, n_frames, utt_model, utt_order, md, tb,       \
+        rc = launch<rq, hh, ntx>(h, Xf, off, E, n_frames, utt_model, utt_order, md, tb,       \
                                  batch_base, lat, scale, replicas, rec_size, st);             \
     } else
     SRX_CASE(0, 1, 1) SRX_CASE(1, 0, 2) SRX_CASE(1, 1, 3) SRX_CASE(2, 0, 4) SRX_CASE(2, 1, 5)
@@ -673,49 +749,6 @@ int srx_fused_estep(srx_context* h, const void* X, const int64_t* off, int64_t U
                        rec_size, out_stats);
     SRX_HIP(hipGetLastError());
     return SRX_OK;
-}
-
-// Processing order that groups the utterances of a model (any order inside a group:
-// an utterance's posteriors do not depend on its neighbours in the batch).
-// (counts and positions are taken in LDS first, one global atomic per model and
-// workgroup: 65,536 atomics on 6 addresses cost 0.2 ms per kernel otherwise)
-constexpr int kOrderModels = 4096;       // LDS histogram entries
-__global__ __launch_bounds__(256) void order_count_kernel(const int32_t* __restrict__ utt_model,
-                                                          int64_t U, int M,
-                                                          unsigned long long* __restrict__ cursor) {
-    __shared__ unsigned hist[kOrderModels];
-    for (int m = threadIdx.x; m < M; m += blockDim.x) hist[m] = 0u;
-    __syncthreads();
-    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (u < U) atomicAdd(&hist[utt_model[u]], 1u);
-    __syncthreads();
-    for (int m = threadIdx.x; m < M; m += blockDim.x)
-        if (hist[m]) atomicAdd(&cursor[m], (unsigned long long)hist[m]);
-}
-__global__ void order_scan_kernel(unsigned long long* cursor, int M) {
-    unsigned long long run = 0;
-    for (int m = 0; m < M; ++m) {
-        const unsigned long long c = cursor[m];
-        cursor[m] = run;
-        run += c;
-    }
-}
-__global__ __launch_bounds__(256) void order_scatter_kernel(const int32_t* __restrict__ utt_model,
-                                                            int64_t U, int M,
-                                                            unsigned long long* __restrict__ cursor,
-                                                            int64_t* __restrict__ order) {
-    __shared__ unsigned hist[kOrderModels];
-    __shared__ unsigned long long first[kOrderModels];
-    for (int m = threadIdx.x; m < M; m += blockDim.x) hist[m] = 0u;
-    __syncthreads();
-    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int m_u = u < U ? utt_model[u] : 0;
-    const unsigned rank = u < U ? atomicAdd(&hist[m_u], 1u) : 0u;
-    __syncthreads();
-    for (int m = threadIdx.x; m < M; m += blockDim.x)
-        if (hist[m]) first[m] = atomicAdd(&cursor[m], (unsigned long long)hist[m]);
-    __syncthreads();
-    if (u < U) order[first[m_u] + rank] = u;
 }
 
 // Posteriors of every frame under its utterance's model with the same kernel
@@ -742,31 +775,22 @@ int srx_fused_posteriors(srx_context* h, const void* X, const int64_t* off, int6
     float *lat, *scale;
     if ((rc = srx_ws_ensure(h, WS_LATTICE, sizeof(float) * (size_t)n_frames * 16, (void**)&lat))) return rc;
     if ((rc = srx_ws_ensure(h, WS_SCALE, sizeof(float) * (size_t)n_frames, (void**)&scale))) return rc;
-    const int64_t n_batches = (U + 15) / 16;
-    int64_t* batch_base;
-    if ((rc = srx_ws_ensure(h, WS_MISC, sizeof(int64_t) * (size_t)n_batches, (void**)&batch_base))) return rc;
     SRX_HIP(hipMemsetAsync(out_lp, 0, sizeof(double) * (size_t)U, st));
     // a batch of 16 utterances is walked once per model present in it: group them
     const int64_t* order = nullptr;
-    if (utt_model != nullptr && M > 1 && M <= kOrderModels) {
-        unsigned long long* cursor;
-        if ((rc = srx_ws_ensure(h, WS_BACKPTR, sizeof(int64_t) * ((size_t)U + (size_t)M), (void**)&cursor))) return rc;
-        int64_t* ord = (int64_t*)(cursor + M);
-        SRX_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned long long) * (size_t)M, st));
-        const unsigned gu = (unsigned)((U + 255) / 256);
-        hipLaunchKernelGGL(order_count_kernel, dim3(gu), dim3(256), 0, st, utt_model, U, M, cursor);
-        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1), 0, st, cursor, M);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3(gu), dim3(256), 0, st, utt_model, U, M, cursor, ord);
-        order = ord;
-    }
+    int64_t E = U;
+    if ((rc = build_model_order(h, utt_model, U, M, st, &order, &E))) return rc;
+    const int64_t n_batches = (E + 15) / 16;
+    int64_t* batch_base;
+    if ((rc = srx_ws_ensure(h, WS_MISC, sizeof(int64_t) * (size_t)n_batches, (void**)&batch_base))) return rc;
     hipLaunchKernelGGL(fused_batch_total_kernel, dim3((unsigned)((n_batches + 255) / 256)), dim3(256),
-                       0, st, off, U, order, n_batches, batch_base);
+                       0, st, off, E, order, n_batches, batch_base);
     hipLaunchKernelGGL(fused_batch_scan_kernel, dim3(1), dim3(1024), 0, st, n_batches, batch_base);
     hipLaunchKernelGGL(fused_prep_kernel, dim3(24), dim3(256), 0, st, *md, RQ, H, base, cst, A, pi);
     const float* Xf = (const float*)X;
 #define SRX_CASE(rq, hh)                                                                         \
     if (RQ == rq && H == hh)                                                                     \
-        return launch<rq, hh, 1, true>(h, Xf, off, U, n_frames, utt_model, order, md, tb,        \
+        return launch<rq, hh, 1, true>(h, Xf, off, E, n_frames, utt_model, order, md, tb,        \
                                        batch_base, lat, scale, nullptr, 0, st, out_post, out_lp);
     SRX_CASE(0, 1) SRX_CASE(1, 0) SRX_CASE(1, 1) SRX_CASE(2, 0) SRX_CASE(2, 1) SRX_CASE(3, 0)
 #undef SRX_CASE

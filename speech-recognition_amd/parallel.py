@@ -65,7 +65,15 @@ class BaumWelchTrainer:
             if um.size and (um.min() < 0 or um.max() >= bank.M):
                 raise ValueError("utt_model entry outside [0, n_models)")
             self.utt_model = ctx.tensor(um)
-            self.utt_order = ctx.tensor(np.argsort(um, kind="stable").astype(np.int64))
+            # Small float32 jobs: no visiting order -- the matrix-core E-step then groups the
+            # utterances by model itself in whole batches of 16 per model, so no batch is
+            # walked twice.  Large jobs (where the few batches that straddle two models do
+            # not matter) and the shape-generic float64 kernels (which keep a model's sums
+            # in registers while the model does not change) get the stable sort, which also
+            # keeps a model's utterances in memory order.
+            small = data.X.dtype == torch.float32 and data.U < 8192
+            self.utt_order = None if small else \
+                ctx.tensor(np.argsort(um, kind="stable").astype(np.int64))
         self.stats = torch.zeros((bank.M, bank.stats_size), dtype=torch.float64, device=ctx.device)
 
     def step(self):
