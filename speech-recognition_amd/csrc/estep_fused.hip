@@ -625,49 +625,63 @@ int launch(srx_context* h, const float* X, const int64_t* off, int64_t U, int64_
 
 }  // namespace
 
-// Processing order that groups the utterances of a model (any order inside a group:
-// an utterance's posteriors do not depend on its neighbours in the batch).
-// (counts and positions are taken in LDS first, one global atomic per model and
-// workgroup: 65,536 atomics on 6 addresses cost 0.2 ms per kernel otherwise)
+// Visiting order that groups the utterances by model, each model's group padded to a
+// multiple of 16 entries (-1 = empty lane) so that no batch of 16 mixes models: a
+// counting sort in three kernels, without atomics on global memory, so that the order
+// -- ascending utterance index inside a model -- is the same on every run and keeps
+// a model's utterances in memory order.
+//   order_hist_kernel     per workgroup of 256 utterances: counts per model
+//   order_offsets_kernel  per model: exclusive prefix of those counts over the workgroups
+//                         (in place) and the model's total
+//   order_bases_kernel    exclusive prefix of the padded totals over the models
+//   order_scatter_kernel  position = model base + workgroup prefix + rank among the
+//                         workgroup's lower-numbered utterances of that model
 constexpr int kOrderModels = 4096;       // LDS histogram entries
-__global__ __launch_bounds__(256) void order_count_kernel(const int32_t* __restrict__ utt_model,
-                                                          int64_t U, int M,
-                                                          unsigned long long* __restrict__ cursor) {
+__global__ __launch_bounds__(256) void order_hist_kernel(const int32_t* __restrict__ utt_model,
+                                                         int64_t U, int M,
+                                                         unsigned* __restrict__ wg_count) {
     __shared__ unsigned hist[kOrderModels];
     for (int m = threadIdx.x; m < M; m += blockDim.x) hist[m] = 0u;
     __syncthreads();
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (u < U) atomicAdd(&hist[utt_model[u]], 1u);
+    if (u < U) atomicAdd(&hist[utt_model[u]], 1u);          // (LDS: the counts do not depend on the order)
     __syncthreads();
-    for (int m = threadIdx.x; m < M; m += blockDim.x)
-        if (hist[m]) atomicAdd(&cursor[m], (unsigned long long)hist[m]);
+    for (int m = threadIdx.x; m < M; m += blockDim.x) wg_count[(size_t)blockIdx.x * M + m] = hist[m];
 }
-// (every model's group starts at a multiple of 16 entries, so that no batch of 16 mixes
-// models; the gaps stay -1 = empty lanes)
-__global__ void order_scan_kernel(unsigned long long* cursor, int M) {
+__global__ void order_offsets_kernel(unsigned* __restrict__ wg_count, int64_t n_wg, int M,
+                                     unsigned long long* __restrict__ total) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    unsigned long long run = 0;
+    for (int64_t w = 0; w < n_wg; ++w) {
+        const unsigned c = wg_count[(size_t)w * M + m];
+        wg_count[(size_t)w * M + m] = (unsigned)run;
+        run += c;
+    }
+    total[m] = run;
+}
+__global__ void order_bases_kernel(unsigned long long* total, int M) {
     unsigned long long run = 0;
     for (int m = 0; m < M; ++m) {
-        const unsigned long long c = cursor[m];
-        cursor[m] = run;
+        const unsigned long long c = total[m];
+        total[m] = run;
         run += (c + 15ull) & ~15ull;
     }
 }
 __global__ __launch_bounds__(256) void order_scatter_kernel(const int32_t* __restrict__ utt_model,
                                                             int64_t U, int M,
-                                                            unsigned long long* __restrict__ cursor,
+                                                            const unsigned* __restrict__ wg_prefix,
+                                                            const unsigned long long* __restrict__ base,
                                                             int64_t* __restrict__ order) {
-    __shared__ unsigned hist[kOrderModels];
-    __shared__ unsigned long long first[kOrderModels];
-    for (int m = threadIdx.x; m < M; m += blockDim.x) hist[m] = 0u;
-    __syncthreads();
+    __shared__ int model_of[256];
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int m_u = u < U ? utt_model[u] : 0;
-    const unsigned rank = u < U ? atomicAdd(&hist[m_u], 1u) : 0u;
+    const int m_u = u < U ? utt_model[u] : -1;
+    model_of[threadIdx.x] = m_u;
     __syncthreads();
-    for (int m = threadIdx.x; m < M; m += blockDim.x)
-        if (hist[m]) first[m] = atomicAdd(&cursor[m], (unsigned long long)hist[m]);
-    __syncthreads();
-    if (u < U) order[first[m_u] + rank] = u;
+    if (u >= U) return;
+    unsigned rank = 0;
+    for (int t = 0; t < (int)threadIdx.x; ++t) rank += model_of[t] == m_u;
+    order[base[m_u] + wg_prefix[(size_t)blockIdx.x * M + m_u] + rank] = u;
 }
 
 // Builds that order in the context's back-pointer scratch (not otherwise used by the
@@ -678,18 +692,23 @@ static int build_model_order(srx_context* h, const int32_t* utt_model, int64_t U
                              hipStream_t st, const int64_t** order, int64_t* entries) {
     *order = nullptr;
     *entries = U;
-    if (utt_model == nullptr || M <= 1 || M > kOrderModels) return SRX_OK;
+    const int64_t n_wg = (U + 255) / 256;
+    if (utt_model == nullptr || M <= 1 || M > kOrderModels || n_wg * M > (int64_t)(1 << 26)) return SRX_OK;
     const int64_t E = (U + 15 * (int64_t)M + 15) / 16 * 16;
-    unsigned long long* cursor;
-    int rc = srx_ws_ensure(h, WS_BACKPTR, sizeof(int64_t) * ((size_t)E + (size_t)M), (void**)&cursor);
+    unsigned long long* total;
+    int rc = srx_ws_ensure(h, WS_BACKPTR,
+                           sizeof(int64_t) * ((size_t)E + (size_t)M) + sizeof(unsigned) * (size_t)n_wg * M,
+                           (void**)&total);
     if (rc) return rc;
-    int64_t* ord = (int64_t*)(cursor + M);
-    SRX_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned long long) * (size_t)M, st));
+    int64_t* ord = (int64_t*)(total + M);
+    unsigned* wg_count = (unsigned*)(ord + E);
     SRX_HIP(hipMemsetAsync(ord, 0xFF, sizeof(int64_t) * (size_t)E, st));
-    const unsigned gu = (unsigned)((U + 255) / 256);
-    hipLaunchKernelGGL(order_count_kernel, dim3(gu), dim3(256), 0, st, utt_model, U, M, cursor);
-    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1), 0, st, cursor, M);
-    hipLaunchKernelGGL(order_scatter_kernel, dim3(gu), dim3(256), 0, st, utt_model, U, M, cursor, ord);
+    hipLaunchKernelGGL(order_hist_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, utt_model, U, M, wg_count);
+    hipLaunchKernelGGL(order_offsets_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, wg_count,
+                       n_wg, M, total);
+    hipLaunchKernelGGL(order_bases_kernel, dim3(1), dim3(1), 0, st, total, M);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, utt_model, U, M,
+                       (const unsigned*)wg_count, (const unsigned long long*)total, ord);
     *order = ord;
     *entries = E;
     return SRX_OK;

@@ -66,11 +66,11 @@ class BaumWelchTrainer:
                 raise ValueError("utt_model entry outside [0, n_models)")
             self.utt_model = ctx.tensor(um)
             # Small float32 jobs: no visiting order -- the matrix-core E-step then groups the
-            # utterances by model itself in whole batches of 16 per model, so no batch is
-            # walked twice.  Large jobs (where the few batches that straddle two models do
-            # not matter) and the shape-generic float64 kernels (which keep a model's sums
-            # in registers while the model does not change) get the stable sort, which also
-            # keeps a model's utterances in memory order.
+            # utterances by model itself (ascending inside a model, whole batches of 16 per
+            # model, so no batch is walked twice; rebuilt on every call, ~0.15 ms at 131,072
+            # utterances).  Large jobs, where the few batches that straddle two models do
+            # not matter, and the shape-generic float64 kernels (which keep a model's sums in
+            # registers while the model does not change) get the stable sort, made once here.
             small = data.X.dtype == torch.float32 and data.U < 8192
             self.utt_order = None if small else \
                 ctx.tensor(np.argsort(um, kind="stable").astype(np.int64))
