@@ -630,3 +630,18 @@ def test_clean_recordings_matches_reference_chunks(sra, ctx, endpoint_golden):
             want = np.concatenate([g[f"cut{i}"] for i in idx])
             np.testing.assert_array_equal(out.astype(np.float32), want)
     assert sra.endpoint.clean_recordings([], 22050, ctx=ctx) == []
+
+
+def test_random_shapes_against_oracle():
+    """tools/fuzz_shapes.py, 60 seeded cases: random numbers of models (1..39), states
+    (1..16), features (1..48), ragged batches with empty utterances, through scoring,
+    Viterbi, posteriors and the E-step in float32 against the numpy oracle (1e-4 relative on
+    log-probabilities, 5e-5 on posteriors and statistics)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_shapes.py"), "60", "5"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "60 cases ok" in r.stdout
