@@ -645,3 +645,19 @@ def test_random_shapes_against_oracle():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "60 cases ok" in r.stdout
+
+
+def test_random_front_end_configurations_against_oracle():
+    """tools/fuzz_mfcc.py, 80 seeded cases: random sample rates, frame lengths, 512 / 1024
+    point transforms, 8..64 filters, 3..16 cepstra, delta orders 0..2 with half-widths 1..3,
+    with and without z-score, ragged batches with signals shorter than a frame, float32
+    against the numpy oracle (1e-4 of the largest value un-normalised, 5e-3 absolute
+    z-scored)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_mfcc.py"), "80", "11"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "80 cases ok" in r.stdout
