@@ -182,11 +182,16 @@ __global__ void fb_chain_kernel(const T* __restrict__ loglik, const int64_t* __r
                                 int64_t U, const int32_t* __restrict__ utt_model,
                                 const int64_t* __restrict__ utt_order, int M, int S,
                                 Tables<T> tb, T* __restrict__ lat, T* __restrict__ scale,
-                                double* __restrict__ partial, double* __restrict__ utt_lp) {
-    extern __shared__ __attribute__((aligned(16))) double acc[];
+                                double* __restrict__ partial, double* __restrict__ utt_lp,
+                                int acc_in_lds) {
+    extern __shared__ __attribute__((aligned(16))) double acc_lds[];
     const int P = S * S + S + 2;
+    // (banks whose M x P sums do not fit the LDS accumulate straight into the workgroup's
+    // own slice of `partial` in global memory)
+    double* acc = acc_in_lds || !partial ? acc_lds : partial + (size_t)blockIdx.x * M * P;
     if (partial) {
         for (int i = threadIdx.x; i < M * P; i += blockDim.x) acc[i] = 0.0;
+        __threadfence_block();
         __syncthreads();
     }
 
@@ -280,7 +285,7 @@ __global__ void fb_chain_kernel(const T* __restrict__ loglik, const int64_t* __r
             }
         }
     }
-    if (!partial) return;
+    if (!partial || !acc_in_lds) return;
     __syncthreads();
     double* dst = partial + (size_t)blockIdx.x * M * P;
     for (int i = threadIdx.x; i < M * P; i += blockDim.x) dst[i] = acc[i];
@@ -946,7 +951,7 @@ int posteriors_t(srx_context* h, const void* X, const int64_t* off, int64_t U, i
     SP_DISPATCH(sp, hipLaunchKernelGGL((fb_chain_kernel<T, SP>),
                                        dim3(grid_for(h, U, kBlock / SP)), dim3(kBlock), 0, st,
                                        (const T*)ll, off, U, utt_model, (const int64_t*)nullptr, M,
-                                       S, tb, (T*)gamma, sc, (double*)nullptr, lp));
+                                       S, tb, (T*)gamma, sc, (double*)nullptr, lp, 1));
     SRX_HIP(hipGetLastError());
     return SRX_OK;
 }
@@ -976,14 +981,14 @@ int estep_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_
                        (void**)&part);
     if (rc) return rc;
     double* part_obs = part + (size_t)g_fb * M * P;
-    const size_t lds = sizeof(double) * (size_t)M * P;
-    SRX_REQUIRE(lds <= 64 * 1024, "estep: %d models x %d states need %zu bytes of LDS (max 65536)",
-                M, S, lds);
+    size_t lds = sizeof(double) * (size_t)M * P;
+    const int acc_in_lds = lds <= 64 * 1024;
+    if (!acc_in_lds) lds = 0;
     hipLaunchKernelGGL(emission_kernel<T>, dim3(grid_for(h, U, 1)), dim3(kBlock), 0, st,
                        (const T*)X, off, U, utt_model, 0, M, S, D, tb, ll);
     SP_DISPATCH(sp, hipLaunchKernelGGL((fb_chain_kernel<T, SP>), dim3(g_fb), dim3(kBlock), lds, st,
                                        (const T*)ll, off, U, utt_model, utt_order, M, S, tb, lat,
-                                       sc, part, (double*)nullptr));
+                                       sc, part, (double*)nullptr, acc_in_lds));
     const int slots = (S * D + kBlock - 1) / kBlock;
     SRX_REQUIRE(slots <= 16, "estep: n_states*n_features = %d exceeds %d", S * D, 16 * kBlock);
 #define OBS(SL)                                                                                   \

@@ -1,5 +1,7 @@
 """Random model / batch shapes through the float32 fast paths against the numpy oracle:
-python tools/fuzz_shapes.py [n_cases] [seed].  Prints the first failure and exits 1."""
+python tools/fuzz_shapes.py [n_cases] [seed] [float32|float64].  Prints the first failure
+and exits 1.  float64 runs the shape-generic kernels (states up to 40) with tolerances a
+million times tighter."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import speech_recognition_amd as sra
@@ -7,13 +9,15 @@ from oracle import hmm_oracle as ho
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+dtype = sys.argv[3] if len(sys.argv) > 3 else "float32"
+tight = 1e-6 if dtype == "float64" else 1.0
 ctx = sra.Context.default(0)
 rng = np.random.default_rng(seed)
 worst = {"score": 0.0, "post": 0.0, "stats": 0.0}
 for case in range(n_cases):
     M = int(rng.integers(1, 9)) if rng.random() < 0.8 else int(rng.integers(9, 40))
-    S = int(rng.integers(1, 17))
-    D = int(rng.integers(1, 49))
+    S = int(rng.integers(1, 17 if dtype == "float32" else 41))
+    D = int(rng.integers(1, 49 if dtype == "float32" else 70))
     U = int(rng.integers(1, 40))
     lengths = rng.integers(0, 60, size=U)
     lengths[rng.integers(0, U)] = int(rng.integers(1, 300))
@@ -22,7 +26,7 @@ for case in range(n_cases):
     um = rng.integers(0, M, size=U).astype(np.int32)
     bank = sra.HMMBank(ctx, np.stack([p.pi for p in prms]), np.stack([p.A for p in prms]),
                        np.stack([p.means for p in prms]), np.stack([p.covars for p in prms]))
-    data = sra.Ragged(ctx, X, lengths, dtype="float32")
+    data = sra.Ragged(ctx, X, lengths, dtype=dtype)
     tag = f"case {case}: M={M} S={S} D={D} U={U} lengths={lengths.tolist()}"
     try:
         sc = bank.score(data).cpu().numpy()
@@ -40,15 +44,15 @@ for case in range(n_cases):
             ref = np.array([ho.score(p, x, [n], loops=False)[0] for p in prms])
             e = np.max(np.abs(sc[u] - ref) / np.abs(ref))
             worst["score"] = max(worst["score"], e)
-            assert e < 1e-4, f"score rel err {e}"
+            assert e < 1e-4 * tight, f"score rel err {e}"
             rl, rg = ho.score_posteriors(prms[um[u]], x, [n], loops=False)
             e = np.abs(gam[off[u]:off[u + 1]] - rg).max()
             worst["post"] = max(worst["post"], e)
-            assert e < 5e-5, f"posterior abs err {e}"
-            assert abs(lp_p[u] - rl[0]) < 1e-4 * abs(rl[0]), "posterior logprob"
+            assert e < 5e-5 * tight, f"posterior abs err {e}"
+            assert abs(lp_p[u] - rl[0]) < 1e-4 * tight * abs(rl[0]), "posterior logprob"
             vlp, vpath = ho.viterbi(prms[um[u]], x, [n])
-            assert abs(lp_v[u] - vlp[0]) < 1e-4 * abs(vlp[0]), "viterbi logprob"
-            assert np.mean(path[off[u]:off[u + 1]] == vpath) > 0.9, "viterbi path"
+            assert abs(lp_v[u] - vlp[0]) < 1e-4 * tight * abs(vlp[0]), "viterbi logprob"
+            assert np.mean(path[off[u]:off[u + 1]] == vpath) > (0.9 if dtype == "float32" else 0.999), "viterbi path"
         for m in range(M):
             sel = [u for u in range(U) if um[u] == m and lengths[u] > 0]
             if not sel:
@@ -61,7 +65,7 @@ for case in range(n_cases):
                 scale = max(1.0, np.abs(ref[k]).max())
                 e = np.abs(st[m][k] - ref[k]).max() / scale
                 worst["stats"] = max(worst["stats"], e)
-                assert e < 5e-5, f"stats {k} err {e}"
+                assert e < 5e-5 * tight, f"stats {k} err {e}"
     except AssertionError as ex:
         print("FAIL", tag, "->", ex)
         sys.exit(1)
