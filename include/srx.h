@@ -88,6 +88,21 @@ typedef struct {
     int32_t delta_n;         /* regression half-width, reference: 2 */
     int32_t zscore;          /* 0 / 1 */
     double log_mult;         /* multiplies log10(mel energy) */
+    /* The fields below select the conventions of librosa.feature.mfcc, the
+     * third-party front-end of extract_mfcc (HMM_lib.py:11-15, HMM_final.py:11-15);
+     * all zero = the reference's own mfcc.py. */
+    int32_t window;          /* 0: symmetric Hamming of frame_len (mfcc.py:21);
+                                1: periodic Hann of frame_len, centred in the nfft points */
+    int32_t center;          /* 0: frame t starts at sample t*hop, tail dropped (mfcc.py:19-20);
+                                1: frame t is the nfft samples centred on t*hop, zeros outside the
+                                   signal, 1 + n/hop frames; 2: the same with reflected samples */
+    int32_t mel_style;       /* 0: HTK mel, triangles between floored bins (mfcc.py:47-61);
+                                1: Slaney mel, triangles over bin frequencies, area-normalised */
+    int32_t power_norm;      /* 0: |X|^2 / nfft (mfcc.py:38); 1: |X|^2 */
+    double log_floor;        /* 0: exact zeros become eps (mfcc.py:43); > 0: energies below it
+                                are raised to it before the logarithm */
+    double top_db;           /* 0: off; > 0: log-mel values of an utterance are raised to
+                                (their maximum - top_db) before the DCT */
 } srx_mfcc_cfg_t;
 
 /* ---- library / context ------------------------------------------------- */

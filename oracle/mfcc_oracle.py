@@ -166,3 +166,107 @@ def extract(signal, cfg):
     """extract_mfcc_calc, HMM_final.py:18-23 (features, then optional z-score)."""
     f = features(signal, cfg)
     return zscore(f) if cfg.zscore else f
+
+
+# ---------------------------------------------------------------------------
+# The OTHER front-end of the reference: extract_mfcc (HMM_lib.py:11-15,
+# HMM_final.py:11-15) = librosa.feature.mfcc(y, sr, n_mfcc=13) with librosa's
+# defaults, then the same StandardScaler.  librosa is a third-party package that
+# the reference neither vendors nor pins (requirements.txt:4 names it without a
+# version) and that is absent from this image, and the reference holds no output
+# of that call: PARITY UNPINNED.  What follows restates the published algorithm of
+# librosa 0.10.x (feature.mfcc -> feature.melspectrogram -> core.stft,
+# filters.mel, core.power_to_db; keyword-only `y=` as the call sites use it came
+# with 0.10, whose stft pads with zeros -- pad_mode="constant"; 0.9 and earlier
+# reflected, offered here as pad_mode="reflect").  librosa keeps the audio, the
+# transform and the filter matrix in float32; this restatement is float64.
+# ---------------------------------------------------------------------------
+@dataclass(frozen=True)
+class LibrosaConfig:
+    sample_rate: int = 22050
+    n_mfcc: int = 13               # HMM_lib.py:11
+    n_fft: int = 2048              # melspectrogram default
+    hop_length: int = 512          # melspectrogram default
+    n_mels: int = 128              # filters.mel default
+    pad_mode: str = "constant"     # stft default since 0.10
+    amin: float = 1e-10            # power_to_db default
+    top_db: float = 80.0           # power_to_db default
+    zscore: bool = True            # HMM_lib.py:14
+
+    def n_frames(self, n_samples):
+        """stft(center=True): one frame per hop, the first centred on sample 0."""
+        return 1 + n_samples // self.hop_length if n_samples > 0 else 0
+
+
+def slaney_hz_to_mel(f):
+    """librosa.hz_to_mel(htk=False): linear below 1 kHz, logarithmic above."""
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz = 1000.0
+    logstep = np.log(6.4) / 27.0
+    lin = f / f_sp
+    with np.errstate(divide="ignore"):
+        log = min_log_hz / f_sp + np.log(np.maximum(f, 1e-300) / min_log_hz) / logstep
+    return np.where(f >= min_log_hz, log, lin)
+
+
+def slaney_mel_to_hz(m):
+    """librosa.mel_to_hz(htk=False)."""
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def slaney_filterbank(sr, n_fft, n_mels=128):
+    """librosa.filters.mel(sr=, n_fft=, n_mels=, fmin=0, fmax=sr/2, htk=False,
+    norm='slaney') -> (n_mels, 1 + n_fft//2): triangles over the bins' centre
+    frequencies, each scaled to unit area (2 / width in Hz)."""
+    fftfreqs = np.linspace(0, sr / 2.0, 1 + n_fft // 2)
+    mel_f = slaney_mel_to_hz(np.linspace(slaney_hz_to_mel(0.0), slaney_hz_to_mel(sr / 2.0), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    fb = np.zeros((n_mels, 1 + n_fft // 2))
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        fb[i] = np.maximum(0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
+    return fb * enorm[:, None]
+
+
+def librosa_melspectrogram(y, cfg):
+    """feature.melspectrogram(power=2.0) -> (T, n_mels): centred frames of n_fft
+    samples (padding per cfg.pad_mode), periodic Hann, |rfft|^2, mel filters."""
+    y = np.asarray(y, dtype=np.float64)
+    N, hop = cfg.n_fft, cfg.hop_length
+    T = cfg.n_frames(len(y))
+    if T == 0:
+        return np.zeros((0, cfg.n_mels))
+    yp = np.pad(y, N // 2, mode=cfg.pad_mode)
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(N) / N)      # get_window('hann', N, fftbins=True)
+    frames = np.stack([yp[t * hop: t * hop + N] for t in range(T)]) * win
+    spec = np.fft.rfft(frames, N)
+    power = spec.real ** 2 + spec.imag ** 2
+    return power @ slaney_filterbank(cfg.sample_rate, N, cfg.n_mels).T
+
+
+def librosa_mfcc(y, cfg):
+    """feature.mfcc(y=, sr=, n_mfcc=) transposed to (T, n_mfcc): power_to_db of the
+    mel spectrogram (ref 1, amin, top_db below the utterance's maximum), DCT-II
+    'ortho' over the mel axis, first n_mfcc rows."""
+    S = librosa_melspectrogram(y, cfg)
+    if S.shape[0] == 0:
+        return np.zeros((0, cfg.n_mfcc))
+    db = 10.0 * np.log10(np.maximum(cfg.amin, S))
+    if cfg.top_db:
+        db = np.maximum(db, db.max() - cfg.top_db)
+    return db @ dct_matrix(cfg.n_mels, cfg.n_mfcc).T
+
+
+def librosa_extract(y, cfg):
+    """extract_mfcc, HMM_lib.py:11-15, after the file has been read."""
+    f = librosa_mfcc(y, cfg)
+    return zscore(f) if cfg.zscore else f

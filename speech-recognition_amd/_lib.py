@@ -45,7 +45,10 @@ class MfccCfg(C.Structure):
     _fields_ = [("sample_rate", C.c_int32), ("frame_len", C.c_int32), ("hop", C.c_int32),
                 ("nfft", C.c_int32), ("n_mel", C.c_int32), ("mel_sample_rate", C.c_int32),
                 ("n_ceps", C.c_int32), ("delta_order", C.c_int32), ("delta_n", C.c_int32),
-                ("zscore", C.c_int32), ("log_mult", C.c_double)]
+                ("zscore", C.c_int32), ("log_mult", C.c_double),
+                # librosa-style conventions (all zero = the reference's mfcc.py)
+                ("window", C.c_int32), ("center", C.c_int32), ("mel_style", C.c_int32),
+                ("power_norm", C.c_int32), ("log_floor", C.c_double), ("top_db", C.c_double)]
 
 
 class EndpointCfg(C.Structure):

@@ -44,13 +44,27 @@ template <> __device__ __forceinline__ double eps_of<double>() { return 2.220446
 struct MfccDev {
     int frame_len, hop, nfft, log2h, n_mel, n_ceps;   // log2h = log2(nfft/2)
     int n_used;                                        // min(frame_len, nfft)
+    int center;                                        // 0 / 1 (zeros) / 2 (reflection)
     const int32_t* mel_ptr;
     const int32_t* mel_bin;
     double log_mult;
+    double power_scale;                                // 1/nfft or 1
+    double log_floor;                                  // 0: exact zeros -> eps
+    void* logmel;                                      // [rows, n_mel] instead of the DCT (top_db)
 };
 
-__device__ __forceinline__ int64_t raw_frames(int64_t n, int L, int hop) {
-    return n < L ? 0 : (n - L) / hop + 1;
+// Frames of an utterance of n samples before the delta trim.  Centred frames
+// (one per hop, the first on sample 0) need no whole frame inside the signal.
+__device__ __forceinline__ int64_t raw_frames(const MfccDev& c, int64_t n) {
+    if (c.center) return n > 0 ? n / c.hop + 1 : 0;
+    return n < c.frame_len ? 0 : (n - c.frame_len) / c.hop + 1;
+}
+
+// Work items and cepstra rows are cut from the packed sample axis.  With centred
+// frames an utterance has a frame ON its end, so it is given one hop of room:
+// utterance u starts at virtual position so[u] + u * hop.
+__device__ __forceinline__ int64_t vpos(const MfccDev& c, const int64_t* so, int64_t u) {
+    return so[u] + (c.center ? u * (int64_t)c.hop : 0);
 }
 
 template <typename T>
@@ -70,6 +84,7 @@ __global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __res
 
     const int64_t chunk = (int64_t)kChunkFrames * c.hop;
     const int64_t n_chunks = (total + chunk - 1) / chunk;
+    // (total = the virtual length, see vpos)
     for (int64_t b = blockIdx.x; b < n_chunks; b += gridDim.x) {
         const int64_t p0 = b * chunk;
         const int64_t p1 = p0 + chunk < total ? p0 + chunk : total;
@@ -77,17 +92,18 @@ __global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __res
         int64_t lo = 0, hi = U;
         while (hi - lo > 1) {
             const int64_t mid = (lo + hi) >> 1;
-            if (so[mid] <= p0) lo = mid; else hi = mid;
+            if (vpos(c, so, mid) <= p0) lo = mid; else hi = mid;
         }
         int item = 0;
-        for (int64_t u = lo; u < U && so[u] < p1; ++u) {
+        for (int64_t u = lo; u < U && vpos(c, so, u) < p1; ++u) {
             const int64_t s0 = so[u], n = so[u + 1] - s0;
-            const int64_t Tu = raw_frames(n, c.frame_len, c.hop);
-            const int64_t a = p0 > s0 ? p0 - s0 : 0;
+            const int64_t v0 = vpos(c, so, u);
+            const int64_t Tu = raw_frames(c, n);
+            const int64_t a = p0 > v0 ? p0 - v0 : 0;
             int64_t ta = (a + c.hop - 1) / c.hop;
-            int64_t tb = (p1 - s0 + c.hop - 1) / c.hop;
+            int64_t tb = (p1 - v0 + c.hop - 1) / c.hop;
             if (tb > Tu) tb = Tu;
-            const int64_t row0 = s0 / c.hop;   // first cepstra row of this utterance
+            const int64_t row0 = v0 / c.hop;   // first cepstra row of this utterance
             for (int64_t t = ta; t < tb; ++t, ++item) {
                 if (item % n_waves != wave) continue;
                 const T* x = audio + s0 + t * c.hop;
@@ -95,8 +111,25 @@ __global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __res
                 for (int k = lane; k < H; k += kWave) {
                     const int n0 = 2 * k, n1 = 2 * k + 1;
                     cplx<T> v;
-                    v.re = n0 < c.n_used ? x[n0] * window[n0] : (T)0;
-                    v.im = n1 < c.n_used ? x[n1] * window[n1] : (T)0;
+                    if (c.center) {
+                        // sample i of the frame is signal sample t*hop - nfft/2 + i
+                        auto at = [&](int i) -> T {
+                            int64_t j = t * c.hop - H + i;
+                            if (c.center == 2) {
+                                if (j < 0) j = -j;
+                                if (j >= n) j = 2 * (n - 1) - j;
+                                j = j < 0 ? 0 : (j >= n ? n - 1 : j);
+                            } else if (j < 0 || j >= n) {
+                                return (T)0;
+                            }
+                            return audio[s0 + j] * window[i];
+                        };
+                        v.re = at(n0);
+                        v.im = at(n1);
+                    } else {
+                        v.re = n0 < c.n_used ? x[n0] * window[n0] : (T)0;
+                        v.im = n1 < c.n_used ? x[n1] * window[n1] : (T)0;
+                    }
                     const int r = (int)(__brev((unsigned)k) >> (32 - c.log2h));
                     z[r] = v;
                 }
@@ -119,7 +152,7 @@ __global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __res
                     wave_sync();
                 }
                 // ---- unpack to the real-input spectrum, power / nfft
-                const T inv_n = (T)1 / (T)c.nfft;
+                const T inv_n = (T)c.power_scale;
                 for (int k = lane; k <= H; k += kWave) {
                     const cplx<T> zk = z[k & (H - 1)];
                     const cplx<T> zc = z[(H - k) & (H - 1)];
@@ -135,10 +168,13 @@ __global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __res
                 for (int m = lane; m < c.n_mel; m += kWave) {
                     T e = 0;
                     for (int q = c.mel_ptr[m]; q < c.mel_ptr[m + 1]; ++q) e += pw[c.mel_bin[q]] * mel_w[q];
-                    if (e == (T)0) e = (T)2.220446049250313e-16;   // np.finfo(float).eps, mfcc.py:43
+                    if (c.log_floor > 0.0) e = e < (T)c.log_floor ? (T)c.log_floor : e;
+                    else if (e == (T)0) e = (T)2.220446049250313e-16;   // np.finfo(float).eps, mfcc.py:43
                     lm[m] = (T)c.log_mult * log10(e);
+                    if (c.logmel) ((T*)c.logmel)[(row0 + t) * c.n_mel + m] = lm[m];
                 }
                 wave_sync();
+                if (c.logmel) continue;         // the DCT follows the utterance-wide clamp
                 // ---- DCT-II rows
                 T* dst = cep + (row0 + t) * c.n_ceps;
                 for (int k = lane; k < c.n_ceps; k += kWave) {
@@ -196,10 +232,10 @@ __global__ void finish_kernel(const T* __restrict__ cep, const int64_t* __restri
     const T inv_den = (T)1 / (T)den;
     for (int64_t u = blockIdx.x; u < U; u += gridDim.x) {
         const int64_t s0 = so[u], n = so[u + 1] - s0;
-        const int64_t Tu = raw_frames(n, c.frame_len, c.hop);
+        const int64_t Tu = raw_frames(c, n);
         const int trim = order > 0 ? N : 0;
         const int64_t To = Tu - 2 * trim > 0 ? Tu - 2 * trim : 0;
-        const T* cu = cep + (s0 / c.hop) * K;
+        const T* cu = cep + (vpos(c, so, u) / c.hop) * K;
         T* ou = out + fo[u] * NF;
         if (To == 0) continue;
         const bool in_lds = Tu * K * (1 + order) <= lds_elems;
@@ -316,11 +352,11 @@ __global__ __launch_bounds__(256) void finish_stream_kernel(
     const T inv_den = (T)1 / (T)den;
     for (int64_t u = blockIdx.x; u < U; u += gridDim.x) {
         const int64_t s0 = so[u], n = so[u + 1] - s0;
-        const int64_t Tu = raw_frames(n, c.frame_len, c.hop);
+        const int64_t Tu = raw_frames(c, n);
         const int trim = order > 0 ? N : 0;
         const int64_t To = Tu - 2 * trim > 0 ? Tu - 2 * trim : 0;
         if (To == 0) continue;
-        const T* cu = cep + (s0 / c.hop) * K;
+        const T* cu = cep + (vpos(c, so, u) / c.hop) * K;
         T* ou = out + fo[u] * NF;
         const int64_t n_tiles = (To + tile_rows - 1) / tile_rows;
         // column sums of a phase -> col_mean (phase 0) or col_scale (phase 1)
@@ -533,6 +569,53 @@ __global__ __launch_bounds__(256) void finish_stream_kernel(
     }
 }
 
+// The clamp of librosa.power_to_db(top_db=...) sits between the logarithm and the
+// DCT and needs the largest log-mel value of the whole utterance: one workgroup per
+// utterance finds it over the stored log-mel rows, then each wave takes frames, raises
+// the row to (maximum - top_db) in its LDS strip and lanes k < n_ceps take DCT row k.
+template <typename T>
+__global__ __launch_bounds__(256) void topdb_dct_kernel(const T* __restrict__ logmel,
+                                                        const int64_t* __restrict__ so, int64_t U,
+                                                        MfccDev c, T top_db,
+                                                        const T* __restrict__ dct, T* __restrict__ cep) {
+    __shared__ T red[256];
+    __shared__ T strip[4][128];
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    for (int64_t u = blockIdx.x; u < U; u += gridDim.x) {
+        const int64_t n = so[u + 1] - so[u];
+        const int64_t Tu = raw_frames(c, n);
+        if (Tu == 0) continue;
+        const int64_t row0 = vpos(c, so, u) / c.hop;
+        const T* lm = logmel + row0 * c.n_mel;
+        const int64_t cnt = Tu * c.n_mel;
+        T m = lm[0];
+        for (int64_t i = threadIdx.x; i < cnt; i += blockDim.x) m = lm[i] > m ? lm[i] : m;
+        red[threadIdx.x] = m;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s && red[threadIdx.x + s] > red[threadIdx.x])
+                red[threadIdx.x] = red[threadIdx.x + s];
+            __syncthreads();
+        }
+        const T thr = red[0] - top_db;
+        for (int64_t t = wave; t < Tu; t += 4) {
+            for (int q = lane; q < c.n_mel; q += kWave) {
+                const T v = lm[t * c.n_mel + q];
+                strip[wave][q] = v < thr ? thr : v;
+            }
+            wave_sync();
+            if (lane < c.n_ceps) {
+                T acc = 0;
+                const T* row = dct + (size_t)lane * c.n_mel;
+                for (int q = 0; q < c.n_mel; ++q) acc += row[q] * strip[wave][q];
+                cep[(row0 + t) * c.n_ceps + lane] = acc;
+            }
+            wave_sync();
+        }
+        __syncthreads();                        // red of the next utterance
+    }
+}
+
 // Launches finish_stream_kernel when delta_n has an instantiation; false otherwise.
 template <typename T>
 bool launch_finish_stream(srx_context* h, const void* cep, const int64_t* so, const int64_t* fo,
@@ -562,9 +645,46 @@ int upload(const std::vector<double>& v, void** dst) {
 }
 
 // Host-side dense filterbank exactly as the reference builds it (mfcc.py:47-61).
+// Slaney's mel scale (linear below 1 kHz, logarithmic above), the default of
+// librosa.filters.mel (htk=False).
+double slaney_hz_to_mel(double f) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, logstep = log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_hz / f_sp + log(f / min_log_hz) / logstep : f / f_sp;
+}
+double slaney_mel_to_hz(double m) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, logstep = log(6.4) / 27.0;
+    const double min_log_mel = min_log_hz / f_sp;
+    return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+
+// librosa.filters.mel(sr, n_fft, n_mels, fmin=0, fmax=sr/2, htk=False, norm='slaney'):
+// triangles over the bins' centre frequencies between n_mel + 2 points equally spaced on
+// the Slaney scale, each scaled by 2 / (width in Hz).
+void build_filterbank_slaney(const srx_mfcc_cfg_t& c, std::vector<double>& fb, int nbins) {
+    const double sr = c.mel_sample_rate;
+    const double m_lo = slaney_hz_to_mel(0.0), m_hi = slaney_hz_to_mel(sr / 2);
+    std::vector<double> f(c.n_mel + 2);
+    for (int i = 0; i < c.n_mel + 2; ++i)
+        f[i] = slaney_mel_to_hz(m_lo + (m_hi - m_lo) * i / (c.n_mel + 1));
+    for (int m = 0; m < c.n_mel; ++m) {
+        const double enorm = 2.0 / (f[m + 2] - f[m]);
+        for (int k = 0; k < nbins; ++k) {
+            const double hz = (sr / 2) * k / (nbins - 1);
+            const double lower = (hz - f[m]) / (f[m + 1] - f[m]);
+            const double upper = (f[m + 2] - hz) / (f[m + 2] - f[m + 1]);
+            const double w = lower < upper ? lower : upper;
+            fb[(size_t)m * nbins + k] = w > 0 ? w * enorm : 0.0;
+        }
+    }
+}
+
 void build_filterbank(const srx_mfcc_cfg_t& c, std::vector<double>& fb, int& nbins) {
     nbins = c.nfft / 2 + 1;
     fb.assign((size_t)c.n_mel * nbins, 0.0);
+    if (c.mel_style == 1) {
+        build_filterbank_slaney(c, fb, nbins);
+        return;
+    }
     const double top = 2595.0 * log10(1.0 + (double)c.mel_sample_rate / 2 / 700);
     std::vector<double> edge(c.n_mel + 2);
     const double step = top / (c.n_mel + 1);
@@ -593,6 +713,13 @@ int check_cfg(const srx_mfcc_cfg_t* c) {
                 c->delta_order);
     SRX_REQUIRE(c->delta_n >= 1 && c->delta_n <= 8, "mfcc: delta_n %d outside [1, 8]", c->delta_n);
     SRX_REQUIRE(c->mel_sample_rate > 0 && c->sample_rate > 0, "mfcc: sample rates must be positive");
+    SRX_REQUIRE(c->window >= 0 && c->window <= 1, "mfcc: window %d outside [0, 1]", c->window);
+    SRX_REQUIRE(c->center >= 0 && c->center <= 2, "mfcc: center %d outside [0, 2]", c->center);
+    SRX_REQUIRE(c->mel_style >= 0 && c->mel_style <= 1, "mfcc: mel_style %d outside [0, 1]", c->mel_style);
+    SRX_REQUIRE(c->power_norm >= 0 && c->power_norm <= 1, "mfcc: power_norm %d outside [0, 1]", c->power_norm);
+    SRX_REQUIRE(c->log_floor >= 0.0 && c->top_db >= 0.0, "mfcc: log_floor and top_db must not be negative");
+    SRX_REQUIRE(!c->center || c->frame_len <= c->nfft,
+                "mfcc: centred frames need frame_len (%d) <= nfft (%d)", c->frame_len, c->nfft);
     return SRX_OK;
 }
 
@@ -601,8 +728,9 @@ int check_cfg(const srx_mfcc_cfg_t* c) {
 extern "C" {
 
 int64_t srx_mfcc_out_frames(const srx_mfcc_cfg_t* c, int64_t n_samples) {
-    if (!c || n_samples < c->frame_len) return 0;
-    const int64_t t = (n_samples - c->frame_len) / c->hop + 1;
+    if (!c) return 0;
+    if (c->center ? n_samples <= 0 : n_samples < c->frame_len) return 0;
+    const int64_t t = c->center ? n_samples / c->hop + 1 : (n_samples - c->frame_len) / c->hop + 1;
     if (c->delta_order == 0) return t;
     return t > 2 * c->delta_n ? t - 2 * c->delta_n : 0;
 }
@@ -623,9 +751,17 @@ int srx_mfcc_plan_create(srx_handle_t h, const srx_mfcc_cfg_t* cfg, srx_mfcc_pla
     const int used = cfg->frame_len < N ? cfg->frame_len : N;   // rfft(frames, NFFT) crops
     std::vector<double> win(cfg->frame_len), tw(2 * (size_t)(H + 1));
     for (int i = 0; i < cfg->frame_len; ++i)
-        win[i] = cfg->frame_len == 1 ? 1.0
+        win[i] = cfg->window == 1 ? 0.5 - 0.5 * cos(2.0 * M_PI * i / cfg->frame_len)
+                 : cfg->frame_len == 1 ? 1.0
                                      : 0.54 - 0.46 * cos(2.0 * M_PI * i / (cfg->frame_len - 1));
     (void)used;
+    if (cfg->center) {
+        // a centred frame always has nfft points: the window sits in their middle
+        std::vector<double> padded(N, 0.0);
+        const int lpad = (N - cfg->frame_len) / 2;
+        for (int i = 0; i < cfg->frame_len; ++i) padded[lpad + i] = win[i];
+        win.swap(padded);
+    }
     for (int k = 0; k <= H; ++k) {
         tw[2 * k] = cos(2.0 * M_PI * k / N);
         tw[2 * k + 1] = -sin(2.0 * M_PI * k / N);
@@ -658,7 +794,9 @@ int srx_mfcc_plan_create(srx_handle_t h, const srx_mfcc_cfg_t* cfg, srx_mfcc_pla
     // mm_nq quads of bins).  One block per group of 4 filters to begin with, then the
     // longest ranges are halved until all 16 blocks are in use.
     p->mm_ok = 0;
-    if (p->fast_ok && cfg->n_mel <= 64 && cfg->n_ceps <= 16 && (N == 512 || N == 1024)) {
+    const bool plain = !cfg->window && !cfg->center && !cfg->power_norm && cfg->log_floor == 0.0 &&
+                       cfg->top_db == 0.0;   // (the register-FFT kernel knows mfcc.py's conventions only)
+    if (plain && p->fast_ok && cfg->n_mel <= 64 && cfg->n_ceps <= 16 && (N == 512 || N == 1024)) {
         struct Blk { int g, lo, hi; };
         const int G = (cfg->n_mel + 3) / 4, PW = H + 4;
         std::vector<Blk> blk;
@@ -809,18 +947,32 @@ int srx_mfcc_batch(srx_handle_t h, srx_mfcc_plan_t p, const void* audio, int dty
     d.n_mel = c.n_mel; d.n_ceps = c.n_ceps;
     d.n_used = c.frame_len < c.nfft ? c.frame_len : c.nfft;
     d.mel_ptr = p->mel_ptr; d.mel_bin = p->mel_bin; d.log_mult = c.log_mult;
+    d.center = c.center;
+    d.power_scale = c.power_norm ? 1.0 : 1.0 / c.nfft;
+    d.log_floor = c.log_floor;
+    d.logmel = nullptr;
+    if (c.center) {
+        d.frame_len = c.nfft;               // the window table is padded to nfft points
+        d.n_used = c.nfft;
+    }
     const size_t esz = dtype == SRX_F64 ? 8 : 4;
-    const int64_t rows = n_samples / c.hop + 1;
+    // cepstra rows and work items live on the virtual sample axis (see vpos)
+    const int64_t v_samples = n_samples + (c.center ? n_utts * (int64_t)c.hop : 0);
+    const int64_t rows = v_samples / c.hop + 1;
     void* cep;
     int rc = srx_ws_ensure(h, WS_CEPSTRA, esz * (size_t)rows * c.n_ceps, &cep);
     if (rc) return rc;
+    if (c.top_db > 0.0) {
+        rc = srx_ws_ensure(h, WS_LOGLIK, esz * (size_t)rows * c.n_mel, &d.logmel);
+        if (rc) return rc;
+    }
     const size_t per_wave = esz * ((size_t)2 * H + (H + 1) + c.n_mel + 1);
     int waves = 4;
     while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
     SRX_REQUIRE(per_wave * waves <= 64 * 1024, "srx_mfcc_batch: nfft %d needs %zu bytes of LDS",
                 c.nfft, per_wave);
     const int64_t chunk = (int64_t)kChunkFrames * c.hop;
-    int64_t n_chunks = (n_samples + chunk - 1) / chunk;
+    int64_t n_chunks = (v_samples + chunk - 1) / chunk;
     int64_t grid = n_chunks < (int64_t)h->n_cu * 16 ? n_chunks : (int64_t)h->n_cu * 16;
     int64_t grid2 = n_utts < (int64_t)h->n_cu * 8 ? n_utts : (int64_t)h->n_cu * 8;
     const int idx = dtype == SRX_F64 ? 1 : 0;
@@ -833,9 +985,13 @@ int srx_mfcc_batch(srx_handle_t h, srx_mfcc_plan_t p, const void* audio, int dty
     if (dtype == SRX_F64) {
         hipLaunchKernelGGL(cepstra_kernel<double>, dim3((unsigned)grid), dim3(waves * kWave),
                            per_wave * waves, st, (const double*)audio, sample_offsets, n_utts,
-                           n_samples, d, (const double*)p->window[idx],
+                           v_samples, d, (const double*)p->window[idx],
                            (const cplx<double>*)p->twiddle[idx], (const double*)p->mel_w[idx],
                            (const double*)p->dct[idx], (double*)cep);
+        if (d.logmel)
+            hipLaunchKernelGGL(topdb_dct_kernel<double>, dim3((unsigned)grid2), dim3(256), 0, st,
+                               (const double*)d.logmel, sample_offsets, n_utts, d, c.top_db,
+                               (const double*)p->dct[idx], (double*)cep);
         if (!launch_finish_stream<double>(h, cep, sample_offsets, frame_offsets, n_utts, d, c, out_feats, st))
             hipLaunchKernelGGL(finish_kernel<double>, dim3((unsigned)grid2), dim3(256), fin_lds, st,
                                (const double*)cep, sample_offsets, frame_offsets, n_utts, d,
@@ -847,11 +1003,15 @@ int srx_mfcc_batch(srx_handle_t h, srx_mfcc_plan_t p, const void* audio, int dty
         if (rc == SRX_EUNSUPPORTED)
             hipLaunchKernelGGL(cepstra_kernel<float>, dim3((unsigned)grid), dim3(waves * kWave),
                                per_wave * waves, st, (const float*)audio, sample_offsets, n_utts,
-                               n_samples, d, (const float*)p->window[idx],
+                               v_samples, d, (const float*)p->window[idx],
                                (const cplx<float>*)p->twiddle[idx], (const float*)p->mel_w[idx],
                                (const float*)p->dct[idx], (float*)cep);
         else if (rc)
             return rc;
+        if (d.logmel)
+            hipLaunchKernelGGL(topdb_dct_kernel<float>, dim3((unsigned)grid2), dim3(256), 0, st,
+                               (const float*)d.logmel, sample_offsets, n_utts, d, (float)c.top_db,
+                               (const float*)p->dct[idx], (float*)cep);
         if (!launch_finish_stream<float>(h, cep, sample_offsets, frame_offsets, n_utts, d, c, out_feats, st))
             hipLaunchKernelGGL(finish_kernel<float>, dim3((unsigned)grid2), dim3(256), fin_lds, st,
                                (const float*)cep, sample_offsets, frame_offsets, n_utts, d,

@@ -68,3 +68,26 @@ def extract_features(signal, sample_rate, dtype="float64"):
     extract_mfcc_calc (HMM_final.py:18-23) without the file read."""
     f, _ = extract_batch([signal], sample_rate, delta_order=1, zscore=True, dtype=dtype)
     return f.astype(np.float64)
+
+
+def librosa_mfcc_batch(signals, sample_rate, n_mfcc=13, *, zscore=False, dtype="float32", ctx=None,
+                       to_host=True, **kw):
+    """``librosa.feature.mfcc(y=, sr=, n_mfcc=)`` conventions (the front-end of
+    extract_mfcc, HMM_lib.py:11-15) for many utterances in one launch; keyword
+    arguments as ``MfccPlan.librosa``.  Returns (packed (sum T, n_mfcc), lengths).
+    librosa itself is not used (it is a third-party package the reference does not
+    pin); this follows the published algorithm of its 0.10 line."""
+    ctx = ctx or Context.default()
+    key = ("librosa", ctx.index, int(sample_rate), int(n_mfcc), bool(zscore)) + tuple(sorted(kw.items()))
+    if key not in _plans:
+        _plans[key] = MfccPlan.librosa(ctx, sample_rate, n_mfcc=n_mfcc, zscore=zscore, **kw)
+    lens = np.array([len(s) for s in signals], dtype=np.int64)
+    so = np.zeros(len(signals) + 1, dtype=np.int64)
+    np.cumsum(lens, out=so[1:])
+    npdt = np.float64 if dtype == "float64" else np.float32
+    packed = np.concatenate([np.asarray(s, dtype=npdt).reshape(-1) for s in signals]) \
+        if len(signals) else np.zeros(0, dtype=npdt)
+    feats, fo = _plans[key].run(packed, so, dtype=dtype)
+    if to_host:
+        feats = feats.cpu().numpy()
+    return feats, np.diff(fo)

@@ -338,18 +338,40 @@ class MfccPlan:
 
     def __init__(self, ctx, sample_rate, frame_size=0.025, frame_stride=0.01, nfft=1024, n_mel=26,
                  mel_sample_rate=16000, n_ceps=13, delta_order=1, delta_n=2, log_mult=20.0,
-                 zscore=True):
+                 zscore=True, frame_len=None, hop=None, window="hamming", center=None,
+                 mel_style="htk", power_norm=False, log_floor=0.0, top_db=0.0):
         self.ctx = ctx
         # mfcc.py:18-19: float products truncated where they are used
-        frame_len, hop = int(frame_size * sample_rate), int(frame_stride * sample_rate)
-        self.cfg = _lib.MfccCfg(int(sample_rate), frame_len, hop, int(nfft), int(n_mel),
+        if frame_len is None:
+            frame_len = int(frame_size * sample_rate)
+        if hop is None:
+            hop = int(frame_stride * sample_rate)
+        try:
+            codes = ({"hamming": 0, "hann": 1}[window], {None: 0, "constant": 1, "reflect": 2}[center],
+                     {"htk": 0, "slaney": 1}[mel_style])
+        except KeyError as e:
+            raise ValueError(f"unknown front-end convention {e.args[0]!r}") from None
+        self.cfg = _lib.MfccCfg(int(sample_rate), int(frame_len), int(hop), int(nfft), int(n_mel),
                                 int(mel_sample_rate), int(n_ceps), int(delta_order), int(delta_n),
-                                int(bool(zscore)), float(log_mult))
+                                int(bool(zscore)), float(log_mult), codes[0], codes[1], codes[2],
+                                int(bool(power_norm)), float(log_floor), float(top_db))
         self.n_feat = int(n_ceps) * (1 + int(delta_order))
         p = C.c_void_p()
         check(lib.srx_mfcc_plan_create(ctx.handle, C.byref(self.cfg), C.byref(p)),
               "srx_mfcc_plan_create")
         self._p = p
+
+    @classmethod
+    def librosa(cls, ctx, sample_rate, n_mfcc=13, n_fft=2048, hop_length=512, n_mels=128,
+                pad_mode="constant", amin=1e-10, top_db=80.0, zscore=True):
+        """The conventions of ``librosa.feature.mfcc(y=, sr=, n_mfcc=)`` as extract_mfcc
+        calls it (HMM_lib.py:11-15): centred frames of n_fft samples every hop_length,
+        periodic Hann, |rfft|^2, Slaney mel filters up to sr/2, 10*log10 floored at amin,
+        raised to (utterance maximum - top_db), DCT-II 'ortho'; no deltas."""
+        return cls(ctx, sample_rate, nfft=n_fft, n_mel=n_mels, mel_sample_rate=sample_rate,
+                   n_ceps=n_mfcc, delta_order=0, log_mult=10.0, zscore=zscore, frame_len=n_fft,
+                   hop=hop_length, window="hann", center=pad_mode, mel_style="slaney",
+                   power_norm=True, log_floor=amin, top_db=top_db or 0.0)
 
     def out_frames(self, n_samples):
         return int(lib.srx_mfcc_out_frames(C.byref(self.cfg), int(n_samples)))
@@ -364,7 +386,12 @@ class MfccPlan:
             raise ValueError(f"sample offsets end at {so[-1]} but audio has {a.numel()} samples")
         lens = np.diff(so)
         L, hop, dn = self.cfg.frame_len, self.cfg.hop, self.cfg.delta_n
-        raw = np.where(lens >= L, (lens - L) // hop + 1, 0)
+        if self.cfg.center:
+            raw = np.where(lens > 0, lens // hop + 1, 0)
+            if self.cfg.center == 2 and (lens <= self.cfg.nfft // 2).any():
+                raise ValueError("reflected padding needs more than nfft/2 samples per utterance")
+        else:
+            raw = np.where(lens >= L, (lens - L) // hop + 1, 0)
         outf = raw if self.cfg.delta_order == 0 else np.maximum(raw - 2 * dn, 0)
         fo = np.zeros(len(lens) + 1, dtype=np.int64)
         np.cumsum(outf, out=fo[1:])
@@ -399,10 +426,10 @@ class MfccPlan:
             self._p = C.c_void_p()
 
 
-def filterbank_host(nfft, mel_sample_rate=16000, n_mel=26):
+def filterbank_host(nfft, mel_sample_rate=16000, n_mel=26, mel_style="htk"):
     """Dense filter matrix as libsrx builds it (no GPU needed)."""
     cfg = _lib.MfccCfg(16000, 400, 160, int(nfft), int(n_mel), int(mel_sample_rate),
-                       min(13, int(n_mel)), 1, 2, 1, 20.0)
+                       min(13, int(n_mel)), 1, 2, 1, 20.0, 0, 0, {"htk": 0, "slaney": 1}[mel_style])
     out = np.zeros((n_mel, nfft // 2 + 1), dtype=np.float64)
     check(lib.srx_mfcc_filterbank_host(C.byref(cfg), out.ctypes.data_as(C.c_void_p)),
           "srx_mfcc_filterbank_host")

@@ -184,3 +184,37 @@ def test_large_model_oracle_pins(hmm_golden):
     mu, var = g[p + "mu"], g[p + "var"]
     ll2 = ho.gmm_log_density(g[p + "X"], np.full((8, 2), 0.5), np.stack([mu, mu], 1), np.stack([var, var], 1))
     np.testing.assert_allclose(ll2, g[p + "loglik"], rtol=1e-12, atol=1e-10)
+
+
+def test_librosa_restatement_invariants():
+    """The librosa-convention oracle has no reference output to be pinned on (librosa is
+    absent; parity unpinned).  What can be checked without it: the one filter value
+    librosa's documentation prints for filters.mel(sr=22050, n_fft=2048) (row 0, bin 1:
+    0.016), unit-area triangles, the frame count of a centred transform, the top_db
+    clamp, and that libsrx builds the same Slaney filter matrix (host code, no GPU)."""
+    from oracle import mfcc_oracle as mo
+    fb = mo.slaney_filterbank(22050, 2048, 128)
+    assert fb.shape == (128, 1025)
+    assert round(float(fb[0, 1]), 3) == 0.016 and fb[0, 0] == 0.0
+    freqs = np.linspace(0, 11025.0, 1025)
+    area = np.array([np.trapezoid(r, freqs) for r in fb[20:]])
+    np.testing.assert_allclose(area, 1.0, atol=0.05)        # sampled triangles, 10.8 Hz bins
+    np.testing.assert_allclose(mo.slaney_mel_to_hz(mo.slaney_hz_to_mel([0.0, 440.0, 1000.0, 8000.0])),
+                               [0.0, 440.0, 1000.0, 8000.0], rtol=1e-12)
+    cfg = mo.LibrosaConfig()
+    assert [cfg.n_frames(n) for n in (0, 1, 511, 512, 20727)] == [0, 1, 1, 2, 41]
+    rng = np.random.default_rng(0)
+    y = 0.1 * rng.standard_normal(12000)
+    y[2000:8000] = 0.0
+    S = mo.librosa_melspectrogram(y, cfg)
+    db = 10 * np.log10(np.maximum(1e-10, S))
+    assert db.min() < db.max() - 80.0                       # the clamp has something to do
+    c = mo.librosa_mfcc(y, cfg)
+    c_noclamp = mo.librosa_mfcc(y, mo.LibrosaConfig(top_db=0.0))
+    assert c.shape == (24, 13) and np.abs(c - c_noclamp).max() > 1.0
+    z = mo.zscore(mo.librosa_mfcc(y, cfg))
+    np.testing.assert_allclose(z.mean(axis=0), 0.0, atol=1e-12)
+    import speech_recognition_amd as sra
+    np.testing.assert_allclose(sra.runtime.filterbank_host(2048, 22050, 128, "slaney"), fb, atol=1e-15)
+    np.testing.assert_allclose(sra.runtime.filterbank_host(1024, 16000, 40, "slaney"),
+                               mo.slaney_filterbank(16000, 1024, 40), atol=1e-15)

@@ -7,8 +7,14 @@ audio = 0.2 * torch.randn((n_utt * n_samp,), device='cuda', dtype=torch.float32)
 so = np.arange(0, (n_utt + 1) * n_samp, n_samp, dtype=np.int64)
 order = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 zs = (sys.argv[2] != "0") if len(sys.argv) > 2 else True
-ref_cfg = len(sys.argv) > 3 and sys.argv[3] == "ref"     # the reference's own configuration
-if ref_cfg:
+ref_cfg = len(sys.argv) > 3 and sys.argv[3] in ("ref", "librosa")   # the reference's own configurations
+lib_cfg = len(sys.argv) > 3 and sys.argv[3] == "librosa"   # extract_mfcc (HMM_lib.py:11-15)
+if lib_cfg:
+    n_samp = 66150
+    audio = 0.2 * torch.randn((n_utt * n_samp,), device='cuda', dtype=torch.float32)
+    so = np.arange(0, (n_utt + 1) * n_samp, n_samp, dtype=np.int64)
+    plan = sra.MfccPlan.librosa(ctx, 22050)
+elif ref_cfg:
     n_samp = 66150                                          # 3 s at 22.05 kHz
     audio = 0.2 * torch.randn((n_utt * n_samp,), device='cuda', dtype=torch.float32)
     so = np.arange(0, (n_utt + 1) * n_samp, n_samp, dtype=np.int64)
@@ -24,4 +30,6 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 5
 L, hop = (551, 220) if ref_cfg else (400, 160)
 frames = n_utt * ((n_samp - L) // hop + 1)
+if lib_cfg:
+    hop, frames = 512, n_utt * (n_samp // 512 + 1)
 print("ms", dt * 1e3, "frames/s", frames / dt, "hbm frac", frames * (hop * 4 + plan.n_feat * 4) / dt / 8e12)
