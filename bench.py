@@ -246,6 +246,25 @@ def main():
                          "ms": dtf * 1e3,
                          "hbm_frac": raw_frames * 796 / dtf / 1e9 / HBM_PEAK_GBS,
                          "config": "16 kHz, 400/160 samples, 512-pt FFT, 40 mel, 13 MFCC+d+dd, z-score"}
+        # the reference's other front-end (extract_mfcc, HMM_lib.py:11-15): librosa's conventions,
+        # 2048-point transform every 512 samples, 128 Slaney filters, top_db clamp, 13 cepstra,
+        # z-score; the same buffer read as 22.05 kHz audio
+        plan_l = sra.MfccPlan.librosa(ctx, 22050)
+        feats_l, fo_l = plan_l.run(audio, so)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            plan_l.run(audio, so, out=feats_l)
+        barrier()
+        dtl = (time.perf_counter() - t0) / reps
+        lib_frames = n_utt_fe * (n_samp // 512 + 1)
+        extra["mfcc_librosa"] = {"frames_per_s": lib_frames * world / dtl, "frames_per_gpu": lib_frames,
+                                 "ms": dtl * 1e3,
+                                 "hbm_frac": lib_frames * (512 * 4 + 13 * 4) / dtl / 1e9 / HBM_PEAK_GBS,
+                                 "config": "librosa.feature.mfcc conventions: 22.05 kHz, centred 2048-pt frames "
+                                           "every 512 samples, Hann, 128 Slaney mel, 10 log10, top_db 80, 13 MFCC, "
+                                           "z-score (generic wave-per-frame kernels)"}
+        del feats_l
         # end-pointing pre-pass over the same recordings (10 ms block energies and
         # zero crossings, thresholds, run search)
         ep = sra.endpoint.detect_batch(audio, so, 16000, ctx=ctx)

@@ -67,6 +67,26 @@ __device__ __forceinline__ int64_t vpos(const MfccDev& c, const int64_t* so, int
     return so[u] + (c.center ? u * (int64_t)c.hop : 0);
 }
 
+// DCT rows of one frame by a whole wave: coefficient k is shared by `parts` adjacent
+// lanes (64 / the next power of two >= n_ceps), each summing every parts-th filter;
+// the partial sums meet by xor shuffles.  lm: the frame's log-mel values in LDS.
+template <typename T>
+__device__ __forceinline__ void dct_rows(const T* __restrict__ dct, const T* lm, int n_mel,
+                                         int n_ceps, int lane, T* __restrict__ dst) {
+    int kp = 1;
+    while (kp < n_ceps) kp <<= 1;               // n_ceps <= 32
+    const int parts = kWave / kp;
+    const int k = lane / parts, part = lane % parts;
+    T acc = 0;
+    if (k < n_ceps) {
+        const T* row = dct + (size_t)k * n_mel;
+#pragma unroll 4
+        for (int m = part; m < n_mel; m += parts) acc += row[m] * lm[m];
+    }
+    for (int o = parts >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
+    if (k < n_ceps && part == 0) dst[k] = acc;
+}
+
 template <typename T>
 __global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __restrict__ so,
                                int64_t U, int64_t total, MfccDev c, const T* __restrict__ window,
@@ -108,6 +128,10 @@ __global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __res
                 if (item % n_waves != wave) continue;
                 const T* x = audio + s0 + t * c.hop;
                 // ---- load, window, pack even/odd samples, bit-reversed store
+                // (the loops of this kernel are unrolled by 4 so that the global and LDS
+                // loads of four iterations are in flight together: one at a time, every
+                // iteration pays a full cache round trip)
+#pragma unroll 4
                 for (int k = lane; k < H; k += kWave) {
                     const int n0 = 2 * k, n1 = 2 * k + 1;
                     cplx<T> v;
@@ -138,6 +162,7 @@ __global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __res
                 for (int s = 0; s < c.log2h; ++s) {
                     const int half = 1 << s;
                     const int tstep = c.nfft >> (s + 1);   // W_H^(pos*H/(2 half)) = W_N^(pos*N/(2 half))
+#pragma unroll 4
                     for (int q = lane; q < (H >> 1); q += kWave) {
                         const int pos = q & (half - 1);
                         const int i = ((q >> s) << (s + 1)) + pos;
@@ -153,6 +178,7 @@ __global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __res
                 }
                 // ---- unpack to the real-input spectrum, power / nfft
                 const T inv_n = (T)c.power_scale;
+#pragma unroll 4
                 for (int k = lane; k <= H; k += kWave) {
                     const cplx<T> zk = z[k & (H - 1)];
                     const cplx<T> zc = z[(H - k) & (H - 1)];
@@ -165,8 +191,14 @@ __global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __res
                 }
                 wave_sync();
                 // ---- mel triangles (CSR), exact zeros -> eps, log_mult * log10
-                for (int m = lane; m < c.n_mel; m += kWave) {
+                // (filters widen with their index: odd rounds hand them out backwards, so
+                // a lane that took a narrow filter takes a wide one next)
+                for (int m0 = 0, rnd = 0; m0 < c.n_mel; m0 += kWave, ++rnd) {
+                    const int cnt = c.n_mel - m0 < kWave ? c.n_mel - m0 : kWave;
+                    if (lane >= cnt) continue;
+                    const int m = m0 + ((rnd & 1) ? cnt - 1 - lane : lane);
                     T e = 0;
+#pragma unroll 4
                     for (int q = c.mel_ptr[m]; q < c.mel_ptr[m + 1]; ++q) e += pw[c.mel_bin[q]] * mel_w[q];
                     if (c.log_floor > 0.0) e = e < (T)c.log_floor ? (T)c.log_floor : e;
                     else if (e == (T)0) e = (T)2.220446049250313e-16;   // np.finfo(float).eps, mfcc.py:43
@@ -176,13 +208,7 @@ __global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __res
                 wave_sync();
                 if (c.logmel) continue;         // the DCT follows the utterance-wide clamp
                 // ---- DCT-II rows
-                T* dst = cep + (row0 + t) * c.n_ceps;
-                for (int k = lane; k < c.n_ceps; k += kWave) {
-                    T acc = 0;
-                    const T* row = dct + (size_t)k * c.n_mel;
-                    for (int m = 0; m < c.n_mel; ++m) acc += row[m] * lm[m];
-                    dst[k] = acc;
-                }
+                dct_rows<T>(dct, lm, c.n_mel, c.n_ceps, lane, cep + (row0 + t) * c.n_ceps);
                 wave_sync();
             }
         }
@@ -604,12 +630,7 @@ __global__ __launch_bounds__(256) void topdb_dct_kernel(const T* __restrict__ lo
                 strip[wave][q] = v < thr ? thr : v;
             }
             wave_sync();
-            if (lane < c.n_ceps) {
-                T acc = 0;
-                const T* row = dct + (size_t)lane * c.n_mel;
-                for (int q = 0; q < c.n_mel; ++q) acc += row[q] * strip[wave][q];
-                cep[(row0 + t) * c.n_ceps + lane] = acc;
-            }
+            dct_rows<T>(dct, strip[wave], c.n_mel, c.n_ceps, lane, cep + (row0 + t) * c.n_ceps);
             wave_sync();
         }
         __syncthreads();                        // red of the next utterance
