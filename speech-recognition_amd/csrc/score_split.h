@@ -91,8 +91,10 @@ __device__ __host__ inline unsigned bf16_rne(float f) {
 // One thread per (row, q, part, lane group): the 8 weights facing the slots
 // [x0 x1 x2 x3 s0 s1 s2 s3] of features 16q+4g .. 16q+4g+3.
 // The feature axis is cut into RQ blocks of 16 (lane group g: features 16q+4g..+3)
-// and, if H, one last block of 8 (lane group g: features 16RQ+2g, +1, in slots
-// 0, 1 and 4, 5; the other slots carry zero weights).
+// and, if H, one last block of 8 (lane group g: features 16RQ+2g, +1).  Its operand
+// carries hi AND lo halves, [xh0 xh1 xl0 xl1 | sh0 sh1 sl0 sl1], so the hi weights are
+// repeated in slots 2, 3 and 6, 7 (w_hi x_hi + w_hi x_lo in one instruction) and the lo
+// weights face zeros there: two instructions per tile for this block instead of three.
 __global__ void split_prep_kernel(srx_models_t md, int SP, int NT, int RQ, int H, unsigned* Wp,
                                   float* cst, float* A, float* pi) {
     const int M = md.n_models, S = md.n_states, D = md.n_features;
@@ -105,7 +107,7 @@ __global__ void split_prep_kernel(srx_models_t md, int SP, int NT, int RQ, int H
         unsigned short v[8];
         for (int j = 0; j < 8; ++j) {
             int d = 16 * q + 4 * g + (j & 3);
-            if (q == RQ) d = (j & 3) < 2 ? 16 * RQ + 2 * g + (j & 3) : D;   // half block
+            if (q == RQ) d = ((j & 3) < 2 || part == 0) ? 16 * RQ + 2 * g + (j & 1) : D;   // half block
             float wv = 0.f;
             if (m < M && s < S && d < D) {
                 const size_t k = ((size_t)m * S + s) * D + d;
@@ -300,29 +302,27 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
                     __builtin_bit_cast(bf16x8, wl[nt][q]), bh, acc[nt], 0, 0, 0);
         }
         if constexpr (H != 0) {
-            // ---- last block of 8 features: two per lane, slots 0, 1 (x) and 4, 5 (x^2)
+            // ---- last block of 8 features: two per lane; hi halves in slots 0, 1 (x) and
+            // 4, 5 (x^2), lo halves in slots 2, 3 and 6, 7
             const float x0 = __uint_as_float(xf.h[0]), x1 = __uint_as_float(xf.h[1]);
             const float s0 = x0 * x0, s1 = x1 * x1;
             const bf16x2 a = {(__bf16)(x0 - __uint_as_float(xf.h[0] & 0xffff0000u)),
                               (__bf16)(x1 - __uint_as_float(xf.h[1] & 0xffff0000u))};
             const bf16x2 b = {(__bf16)(s0 - __uint_as_float(__float_as_uint(s0) & 0xffff0000u)),
                               (__bf16)(s1 - __uint_as_float(__float_as_uint(s1) & 0xffff0000u))};
-            const u32x4 fh = {__builtin_amdgcn_perm(xf.h[1], xf.h[0], 0x07060302u), 0u,
-                              __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u), 0u};
-            const u32x4 fl = {__builtin_bit_cast(unsigned, a), 0u, __builtin_bit_cast(unsigned, b), 0u};
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, fh), bl = __builtin_bit_cast(bf16x8, fl);
+            const u32x4 fb = {__builtin_amdgcn_perm(xf.h[1], xf.h[0], 0x07060302u),
+                              __builtin_bit_cast(unsigned, a),
+                              __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u),
+                              __builtin_bit_cast(unsigned, b)};
+            const bf16x8 bb = __builtin_bit_cast(bf16x8, fb);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, wh[nt][RQ]), bh, acc[nt], 0, 0, 0);
+                    __builtin_bit_cast(bf16x8, wh[nt][RQ]), bb, acc[nt], 0, 0, 0);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, wh[nt][RQ]), bl, acc[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, wl[nt][RQ]), bh, acc[nt], 0, 0, 0);
+                    __builtin_bit_cast(bf16x8, wl[nt][RQ]), bb, acc[nt], 0, 0, 0);
         }
         // ---- recursion, all tiles stage by stage (independent chains interleave)
         const bool live = t < T;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
         // vector instructions, repeated.  The matrix pipe runs beside the vector
         // pipe only where the stream alternates between them.
 #pragma unroll
-        for (int i = 0; i < PF * (QT * 3 * NT + 2 * NT); ++i) {
+        for (int i = 0; i < PF * ((RQ * 3 + H * 2) * NT + 2 * NT); ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         }
