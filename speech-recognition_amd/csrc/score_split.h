@@ -418,16 +418,11 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
         for (int k = 0; k < PF; ++k) {
             step(std::false_type{}, std::false_type{}, t0 + k, xq[(1 + k) % PF], lpf);
             load(t0 + k + PF, xq[(1 + k) % PF]);
+            // memory instructions stay on their side of this point (everything else may
+            // cross): the loads of a step are issued before the next step begins
+            __builtin_amdgcn_sched_barrier(0x78F);
         }
         fold(lpf);
-        // Scheduling request for this loop body: one matrix instruction, then four
-        // vector instructions, repeated.  The matrix pipe runs beside the vector
-        // pipe only where the stream alternates between them.
-#pragma unroll
-        for (int i = 0; i < PF * ((RQ * 3 + H * 2) * NT + 2 * NT); ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        }
     }
     for (; t0 < Tmax; t0 += PF) {
 #pragma unroll
