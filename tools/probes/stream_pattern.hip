@@ -70,18 +70,20 @@ __global__ __launch_bounds__(256) void k_seq(const u32x4* X, int64_t n, float* o
 }
 
 template <int BURST>
-void run(const float* X, int64_t U, int T, int D, float* out) {
+void run(const float* X, int64_t U, int T, int D, float* out, int lds = 0) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const unsigned grid = (unsigned)((U / 16 + 3) / 4);
-    k<BURST><<<grid, 256>>>(X, U, T, D, out);
+    k<BURST><<<grid, 256, lds>>>(X, U, T, D, out);
     (void)hipEventRecord(e0);
-    for (int i = 0; i < 10; ++i) k<BURST><<<grid, 256>>>(X, U, T, D, out);
+    for (int i = 0; i < 10; ++i) k<BURST><<<grid, 256, lds>>>(X, U, T, D, out);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     ms /= 10;
-    printf("burst %d rows: %.4f ms  %.3f TB/s\n", BURST, ms, (double)U * T * D * 4 / ms / 1e9);
+    printf("burst %d rows, %s: %.4f ms  %.3f TB/s\n", BURST,
+           lds >= 65536 ? "2 waves/SIMD (the scoring kernel's occupancy)" : lds >= 40000 ? "3 waves/SIMD" : "4 waves/SIMD",
+           ms, (double)U * T * D * 4 / ms / 1e9);
 }
 
 int main() {
@@ -108,6 +110,12 @@ int main() {
         run<2>(X, U, T, D, out);
         run<4>(X, U, T, D, out);
         run<8>(X, U, T, D, out);
+    }
+    // the same with the occupancy held down by an unused LDS allocation per workgroup
+    for (int lds = 48 * 1024; lds <= 64 * 1024; lds += 16 * 1024) {
+        run<1>(X, U, T, D, out, lds);
+        run<2>(X, U, T, D, out, lds);
+        run<4>(X, U, T, D, out, lds);
     }
     return 0;
 }
