@@ -249,6 +249,16 @@ int srx_estep_stats_generic(srx_handle_t h, const void* X, int dtype, const int6
                             const int64_t* utt_order, const srx_models_t* models,
                             double* out_stats, void* stream);
 
+/* ---- multi-GPU: the one exchange step of the path.  do_estep sums the statistics of
+ * all utterances (hmm.py:427-432); with the utterances sharded over ranks (one process
+ * per GPU) that sum is completed by ONE all-reduce of the packed float64 records of all
+ * models per EM iteration, after which srx_mstep runs replicated on identical sums.  The
+ * reference has no distributed code.  `nccl_comm` is the caller's ncclComm_t (RCCL);
+ * the library binds to the RCCL already loaded in the process (else librccl.so.1) at the
+ * first call and enqueues ncclAllReduce(stats, stats, count, ncclDouble, ncclSum) on the
+ * stream.  In place; `count` doubles (n_models * srx_stats_size). */
+int srx_allreduce_stats(srx_handle_t h, void* nccl_comm, double* stats, int64_t count, void* stream);
+
 /* ---- M-step: do_em_mstep (hmm.py:435-451) and do_mstep (hmm.py:165-184),
  * applied in place to every model of the bank from its statistics record. */
 int srx_mstep(srx_handle_t h, const double* stats, const srx_priors_t* priors, int mode,

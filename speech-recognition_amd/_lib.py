@@ -81,6 +81,7 @@ SIGNATURES = {
     "srx_viterbi": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, _vp, C.POINTER(Models), _vp, _vp, _vp]),
     "srx_estep_stats": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, _vp, _vp, C.POINTER(Models), _vp, _vp]),
     "srx_estep_stats_generic": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, _vp, _vp, C.POINTER(Models), _vp, _vp]),
+    "srx_allreduce_stats": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "srx_mstep": (C.c_int, [_vp, _vp, C.POINTER(Priors), C.c_int, C.POINTER(Models), _vp]),
     "srx_gmm_emission_loglik": (C.c_int, [_vp, _vp, C.c_int, _i64, C.POINTER(Gmm), _vp, _vp]),
     "srx_posteriors": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, _vp, C.POINTER(Models), _vp, _vp, _vp]),

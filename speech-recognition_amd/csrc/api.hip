@@ -1,6 +1,8 @@
 // C ABI of libsrx: context, argument checks and dispatch to the kernels.
 #include "srx_internal.h"
 
+#include <dlfcn.h>
+
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -115,6 +117,54 @@ int64_t srx_workspace_bytes(srx_handle_t h) {
     int64_t s = 0;
     for (int i = 0; i < WS_NUM; ++i) s += (int64_t)h->ws_bytes[i];
     return s;
+}
+
+// RCCL is bound at run time: a process that already holds one (torch ships its own copy)
+// must not get a second, and a single-GPU caller needs none at all.
+namespace {
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*nccl_errstr_fn)(int);
+nccl_allreduce_fn g_allreduce = nullptr;
+nccl_errstr_fn g_errstr = nullptr;
+
+int bind_rccl() {
+    if (g_allreduce) return SRX_OK;
+    void* lib = nullptr;
+    const char* names[] = {"librccl.so", "librccl.so.1"};
+    for (const char* n : names)
+        if (!lib) lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // the copy already in the process
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) {
+        srx_set_error("srx_allreduce_stats: no RCCL library (%s)", dlerror());
+        return SRX_EUNSUPPORTED;
+    }
+    g_errstr = (nccl_errstr_fn)dlsym(lib, "ncclGetErrorString");
+    nccl_allreduce_fn f = (nccl_allreduce_fn)dlsym(lib, "ncclAllReduce");
+    if (!f) {
+        srx_set_error("srx_allreduce_stats: ncclAllReduce not found in the RCCL library");
+        return SRX_EUNSUPPORTED;
+    }
+    g_allreduce = f;
+    return SRX_OK;
+}
+}  // namespace
+
+int srx_allreduce_stats(srx_handle_t h, void* nccl_comm, double* stats, int64_t count, void* stream) {
+    SRX_REQUIRE(h != nullptr, "srx_allreduce_stats: NULL context");
+    SRX_REQUIRE(count >= 0, "srx_allreduce_stats: negative count");
+    if (count == 0) return SRX_OK;
+    SRX_REQUIRE(nccl_comm != nullptr && stats != nullptr, "srx_allreduce_stats: NULL communicator or buffer");
+    int rc = bind_rccl();
+    if (rc) return rc;
+    SRX_HIP(hipSetDevice(h->device));
+    const int kNcclDouble = 8, kNcclSum = 0;                     // ncclFloat64, ncclSum (nccl.h)
+    const int res = g_allreduce(stats, stats, (size_t)count, kNcclDouble, kNcclSum, nccl_comm,
+                                (hipStream_t)stream);
+    if (res != 0) {
+        srx_set_error("srx_allreduce_stats: ncclAllReduce failed: %s", g_errstr ? g_errstr(res) : "?");
+        return SRX_EHIP;
+    }
+    return SRX_OK;
 }
 
 int64_t srx_stats_size(int32_t n_states, int32_t n_features) {

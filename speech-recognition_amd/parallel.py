@@ -46,6 +46,17 @@ def allreduce_stats(stats):
     return stats
 
 
+def allreduce_stats_rccl(ctx, nccl_comm, stats):
+    """The same sum through the C ABI (srx_allreduce_stats) for hosts that hold a raw
+    ncclComm_t instead of a torch process group; nccl_comm is the communicator's
+    address.  Enqueued on the current stream, in place."""
+    import ctypes as C
+    from ._lib import lib, check
+    check(lib.srx_allreduce_stats(ctx.handle, C.c_void_p(int(nccl_comm)), C.c_void_p(stats.data_ptr()),
+                                  int(stats.numel()), ctx.stream_ptr()), "srx_allreduce_stats")
+    return stats
+
+
 class BaumWelchTrainer:
     """Batched EM for a bank of models over this rank's shard of utterances.
 
