@@ -10,6 +10,14 @@
 #define OP_MAX(r) asm volatile("v_max_f32 %0, %1, %0" : "+v"(r) : "v"(x));
 #define OP_MAX3(r) asm volatile("v_max3_f32 %0, %1, %2, %0" : "+v"(r) : "v"(x), "v"(y));
 #define OP_AND(r) asm volatile("v_and_b32 %0, %1, %0" : "+v"(r) : "v"(x));
+#define OP_ANDLIT(r) asm volatile("v_and_b32 %0, 0xffff0000, %0" : "+v"(r));
+#define OP_ANDSGPR(r) asm volatile("v_and_b32 %0, %1, %0" : "+v"(r) : "s"(sm));
+#define OP_SUBSGPR(r) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(r) : "s"(sm));
+#define OP_ADDLIT(r) asm volatile("v_add_f32 %0, 0x3f99999a, %0" : "+v"(r));
+#define OP_ADDINL(r) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(r));
+#define OP_FMA3(r) asm volatile("v_fma_f32 %0, %1, %1, -%0" : "+v"(r) : "v"(x));
+#define OP_PERMSGPR(r) asm volatile("v_perm_b32 %0, %1, %0, %2" : "+v"(r) : "v"(x), "s"(sm));
+#define OP_SUBE64(r) asm volatile("v_sub_f32_e64 %0, %1, %0" : "+v"(r) : "v"(x));
 #define OP_PERM(r) asm volatile("v_perm_b32 %0, %1, %0, %2" : "+v"(r) : "v"(x), "v"(y));
 #define OP_CVTPK(r) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %0" : "+v"(r) : "v"(x));
 #define OP_DOT2C(r) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(r) : "v"(x), "v"(y));
@@ -35,11 +43,12 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define KERNEL(NAME, OP)                                                              \
     __global__ __launch_bounds__(256) void k_##NAME(float* out, int iters) {          \
         float r0 = threadIdx.x, r1 = 1, r2 = 2, r3 = 3, r4 = 4, r5 = 5, x = 0.999f, y = 1e-3f; \
+        unsigned sm = 0xffff0000u; asm volatile("" : "+s"(sm));                       \
         f2 pr0 = {r0, 1}, pr1 = pr0, pr2 = pr0, pr3 = pr0, pr4 = pr0, pr5 = pr0, px = {x, y};  \
         for (int it = 0; it < iters; ++it) { REP48(OP) }                              \
         out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + x + pr0[0] + pr1[1] + pr2[0] + pr3[1] + pr4[0] + pr5[1]; \
     }
-#define LIST(X) X(FMA) X(FMAC) X(ADD) X(SUB) X(MUL) X(MULLEG) X(MAX) X(MAX3) X(AND) X(LSHL) X(BFI) X(ADDU) X(PERM) X(CVTPK) X(CVTF16) \
+#define LIST(X) X(FMA) X(FMAC) X(ADD) X(SUB) X(MUL) X(MULLEG) X(MAX) X(MAX3) X(AND) X(ANDLIT) X(ANDSGPR) X(SUBSGPR) X(SUBE64) X(ADDLIT) X(ADDINL) X(FMA3) X(PERMSGPR) X(LSHL) X(BFI) X(ADDU) X(PERM) X(CVTPK) X(CVTF16) \
     X(DOT2C) X(MOV) X(CNDMASK) X(EXP) X(LOG) X(PKMUL) X(PKFMA) X(PKADD) X(PKADDF16) X(PKMAXF16) X(SWAP) X(DPP)
 #define DEF(N) KERNEL(N, OP_##N)
 LIST(DEF)
