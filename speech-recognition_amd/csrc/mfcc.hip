@@ -158,21 +158,46 @@ __global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __res
                     z[r] = v;
                 }
                 wave_sync();
-                // ---- radix-2 DIT, H points; tw[k] = exp(-2 pi i k / nfft)
-                for (int s = 0; s < c.log2h; ++s) {
-                    const int half = 1 << s;
-                    const int tstep = c.nfft >> (s + 1);   // W_H^(pos*H/(2 half)) = W_N^(pos*N/(2 half))
+                // ---- DIT over H points on the bit-reversed tile; tw[k] = exp(-2 pi i k / nfft).
+                // Two radix-2 stages are taken together as one radix-4 pass (half the LDS
+                // round trips and wave syncs): in the second of the two, the lower pair's
+                // twiddle is the upper pair's times W^(nfft/4) = -i, so a pass loads two
+                // twiddles for four points.  An odd stage count starts with one radix-2 stage.
+                int s0st = 0;
+                if (c.log2h & 1) {
 #pragma unroll 4
                     for (int q = lane; q < (H >> 1); q += kWave) {
-                        const int pos = q & (half - 1);
-                        const int i = ((q >> s) << (s + 1)) + pos;
-                        const int j = i + half;
-                        const cplx<T> w = tw[pos * tstep];
+                        const int i = q << 1, j = i + 1;          // (twiddle 1)
                         const cplx<T> zi = z[i], zj = z[j];
-                        const T tr = w.re * zj.re - w.im * zj.im;
-                        const T ti = w.re * zj.im + w.im * zj.re;
-                        z[i].re = zi.re + tr; z[i].im = zi.im + ti;
-                        z[j].re = zi.re - tr; z[j].im = zi.im - ti;
+                        z[i].re = zi.re + zj.re; z[i].im = zi.im + zj.im;
+                        z[j].re = zi.re - zj.re; z[j].im = zi.im - zj.im;
+                    }
+                    wave_sync();
+                    s0st = 1;
+                }
+                for (int s = s0st; s < c.log2h; s += 2) {
+                    const int half = 1 << s;
+                    const int ts1 = c.nfft >> (s + 1), ts2 = c.nfft >> (s + 2);
+#pragma unroll 4
+                    for (int q = lane; q < (H >> 2); q += kWave) {
+                        const int pos = q & (half - 1);
+                        const int i0 = ((q >> s) << (s + 2)) + pos;
+                        const cplx<T> w1 = tw[pos * ts1], w2 = tw[pos * ts2];
+                        const cplx<T> x0 = z[i0], x1 = z[i0 + half], x2 = z[i0 + 2 * half],
+                                      x3 = z[i0 + 3 * half];
+                        // first stage of the pass: (x0, x1) and (x2, x3) with w1
+                        const T t1r = w1.re * x1.re - w1.im * x1.im, t1i = w1.re * x1.im + w1.im * x1.re;
+                        const T t3r = w1.re * x3.re - w1.im * x3.im, t3i = w1.re * x3.im + w1.im * x3.re;
+                        const T a0r = x0.re + t1r, a0i = x0.im + t1i, a1r = x0.re - t1r, a1i = x0.im - t1i;
+                        const T a2r = x2.re + t3r, a2i = x2.im + t3i, a3r = x2.re - t3r, a3i = x2.im - t3i;
+                        // second stage: (a0, a2) with w2, (a1, a3) with -i w2
+                        const T u2r = w2.re * a2r - w2.im * a2i, u2i = w2.re * a2i + w2.im * a2r;
+                        const T vr = w2.re * a3r - w2.im * a3i, vi = w2.re * a3i + w2.im * a3r;
+                        const T u3r = vi, u3i = -vr;
+                        z[i0].re = a0r + u2r;            z[i0].im = a0i + u2i;
+                        z[i0 + half].re = a1r + u3r;     z[i0 + half].im = a1i + u3i;
+                        z[i0 + 2 * half].re = a0r - u2r; z[i0 + 2 * half].im = a0i - u2i;
+                        z[i0 + 3 * half].re = a1r - u3r; z[i0 + 3 * half].im = a1i - u3i;
                     }
                     wave_sync();
                 }
