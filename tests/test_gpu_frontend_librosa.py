@@ -103,3 +103,51 @@ def test_hmm_lib_harness_end_to_end(sra, tmp_path):
     assert sorted(again) == ["alpha", "beta"]
     assert L.recognize_lib(again, files[0], 22050) == "alpha"
     assert L.recognize_lib(again, files[-1], 22050) == "beta"
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 2e-4)])
+def test_librosa_conventions_random_configurations(sra, dtype, tol):
+    """40 seeded random configurations: transform sizes 64 .. 4096 (odd and even stage
+    counts of the LDS transform), hops, filter and cepstrum counts, both paddings, clamp on
+    or off, ragged batches with empty and one-sample utterances."""
+    rng = np.random.default_rng(17)
+    for case in range(40):
+        n_fft = int(rng.choice([64, 128, 256, 512, 1024, 2048, 4096]))
+        hop = int(rng.integers(max(n_fft // 8, 1), n_fft + 1))
+        n_mels = int(rng.integers(8, min(128, n_fft // 4) + 1))
+        n_mfcc = int(rng.integers(2, min(32, n_mels) + 1))
+        sr = int(rng.choice([8000, 16000, 22050, 44100]))
+        pad_mode = str(rng.choice(["constant", "reflect"]))
+        top_db = float(rng.choice([0.0, 40.0, 80.0]))
+        zs = bool(rng.integers(0, 2))
+        lo = n_fft // 2 + 1 if pad_mode == "reflect" else 0
+        lens = [int(rng.integers(lo, lo + 4 * n_fft + 3000)) for _ in range(int(rng.integers(1, 6)))]
+        if pad_mode == "constant":
+            lens += [0, 1]
+        sigs = []
+        for n in lens:
+            t = np.arange(n) / sr
+            s = 0.05 * rng.standard_normal(n) + 0.2 * np.sin(2 * np.pi * rng.uniform(80, 3000) * t)
+            if n > 2000 and rng.random() < 0.5:
+                s[n // 4: n // 2] = 0.0
+            sigs.append(s.astype(np.float32).astype(np.float64) if dtype == "float32" else s)
+        cfg = mo.LibrosaConfig(sample_rate=sr, n_mfcc=n_mfcc, n_fft=n_fft, hop_length=hop, n_mels=n_mels,
+                               pad_mode=pad_mode, top_db=top_db, zscore=zs)
+        f, ln = sra.mfcc.librosa_mfcc_batch(sigs, sr, n_mfcc, zscore=zs, dtype=dtype, n_fft=n_fft,
+                                            hop_length=hop, n_mels=n_mels, pad_mode=pad_mode, top_db=top_db)
+        tag = f"case {case}: n_fft={n_fft} hop={hop} n_mels={n_mels} n_mfcc={n_mfcc} sr={sr} {pad_mode} top_db={top_db} z={zs} lens={lens}"
+        assert list(ln) == [cfg.n_frames(n) for n in lens], tag
+        off = np.concatenate([[0], np.cumsum(ln)])
+        for k, s in enumerate(sigs):
+            ref = mo.librosa_extract(s, cfg)
+            got = f[off[k]:off[k + 1]]
+            assert got.shape == ref.shape, tag
+            if ref.size == 0:
+                continue
+            if zs:
+                # z-scores divide by a column's spread: compare where the column has one
+                ok = mo.librosa_mfcc(s, cfg).std(axis=0) > 1e-6 * np.abs(mo.librosa_mfcc(s, cfg)).max()
+                err = np.abs(got - ref)[:, ok].max() if ok.any() else 0.0
+                assert err <= (1e-6 if dtype == "float64" else 2e-2), (tag, k, err)
+            else:
+                assert np.abs(got - ref).max() <= tol * np.abs(ref).max(), (tag, k)
