@@ -224,6 +224,23 @@ def main():
                                "config": "state posteriors, one 8-state model per utterance (u mod 6), "
                                          "float32 (156 B in + 32 B out per frame)"}
         del plp, pgam, um
+        # the headline workload in the validation dtype: float64 features, every product of
+        # the emission contraction on the f64 matrix instruction
+        X64 = X.double()
+        data64 = sra.Ragged(ctx, X64, offsets=data.offsets, dtype="float64")
+        sc64 = bank.score(data64)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            bank.score(data64, out=sc64)
+        barrier()
+        dt64 = (time.perf_counter() - t0) / 3
+        extra["score_f64"] = {"frames_per_s": n_fr * world / dt64, "ms": dt64 * 1e3,
+                              "hbm_frac": n_fr * N_FEAT * 8 / dt64 / 1e9 / HBM_PEAK_GBS,
+                              "max_rel_diff_vs_f32": float(((sc64 - scores).abs() / sc64.abs()).max().item()),
+                              "config": "the same 65,536 x 200 x 39 frames and 6 x 8-state models in float64 "
+                                        "(312 B in per frame, one pass over X per tile of two models)"}
+        del X64, data64, sc64
         del X, data
         torch.cuda.empty_cache()
         # front-end: 16 kHz, 25/10 ms, 512-pt FFT, 40 mel, 13 ceps + delta + delta-delta

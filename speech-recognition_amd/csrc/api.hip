@@ -199,6 +199,10 @@ int srx_forward_score(srx_handle_t h, const void* X, int dtype, const int64_t* u
         rc = srx_mfma_score(h, X, utt_offsets, n_utts, n_frames, models, out_scores,
                             (hipStream_t)stream);
         if (rc != SRX_EUNSUPPORTED) return rc;
+    } else {
+        rc = srx_mfma_score_f64(h, X, utt_offsets, n_utts, n_frames, models, out_scores,
+                                (hipStream_t)stream);
+        if (rc != SRX_EUNSUPPORTED) return rc;
     }
     return srx_generic_score(h, X, dtype, utt_offsets, n_utts, n_frames, models, out_scores,
                              (hipStream_t)stream);

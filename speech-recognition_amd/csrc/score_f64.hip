@@ -1,0 +1,239 @@
+// Float64 scoring on the matrix cores: emission log-densities and the scaled forward
+// recursion in one pass over X, every multiply-add of the emission contraction a
+// v_mfma_f64_16x16x4_f64.  This is the validation dtype (results agree with the
+// reference's float64 arithmetic to rounding) at a rate the shape-generic kernels cannot
+// reach: on gfx950 the f64 matrix instruction costs less than twice the f32 one.
+//
+// Emission as a contraction, per frame x and state column c (log2 units throughout):
+//     ll2[c] = cst[c] + sum_d  x_d * (mu/var * log2e) + x_d^2 * (-1/(2 var) * log2e)
+// Wave geometry: one wave scores 16 utterances against ONE tile of 16 state columns
+// (4 models of <= 4 states or 2 models of <= 8 states), time step by time step; the
+// tiles of a bank are the grid's y axis and each re-reads X.  Matrix columns are
+// utterances.  The f64 instruction spreads its 16 result rows differently from the f32
+// one: register r of lane group g (= lane / 16) is row 4r + g.  State columns are
+// therefore placed so that row 4r + g is "logical column" 4g + r = (model 4g/SP, state
+// (4g + r) mod SP): a lane then holds four consecutive states of one model, and a model
+// of 8 states sits in lanes l and l ^ 16, as in the float32 kernels.  The A operand of
+// lane (g, ul) is the weight of row ul, i.e. of logical column 4 (ul & 3) + (ul >> 2).
+// The B operand of k-step q comes from lane group g: q = 4r + e is feature
+// d = 8r + 2g + (e & 1), x_d for e < 2 and x_d^2 for e >= 2.
+#include "srx_internal.h"
+
+#include <math.h>
+
+namespace {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr double kLn2 = 0.6931471805599453;
+constexpr double kLog2e = 1.4426950408889634;
+constexpr double kNegBig = -1.0e300;
+
+struct F64Tables {
+    const double* W;     // [n_tiles*16 logical columns][4R][4 lane groups]
+    const double* cst;   // [n_tiles*16]
+};
+
+__global__ void f64_prep_kernel(srx_models_t md, int SP, int n_tiles, int R, double* W, double* cst) {
+    const int M = md.n_models, S = md.n_states, D = md.n_features;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nth = gridDim.x * blockDim.x;
+    const int KQ = 4 * R;
+    for (int i = tid; i < n_tiles * 16 * KQ * 4; i += nth) {
+        const int g = i & 3, q = (i >> 2) % KQ, col = (i >> 2) / KQ;
+        const int m = col / SP, s = col % SP;
+        const int r = q >> 2, e = q & 3;
+        const int d = 8 * r + 2 * g + (e & 1);
+        double v = 0.0;
+        if (m < M && s < S && d < D) {
+            const size_t k = ((size_t)m * S + s) * D + d;
+            const double var = fmax(md.covars[k], 2.2250738585072014e-308);
+            v = (e >> 1) ? (-0.5 / var) * kLog2e : (md.means[k] / var) * kLog2e;
+        }
+        W[i] = v;
+    }
+    const int wave = tid >> 6, lane = tid & 63, n_wave = nth >> 6;
+    for (int col = wave; col < n_tiles * 16; col += n_wave) {
+        const int m = col / SP, s = col % SP;
+        const bool on = m < M && s < S;
+        double acc = 0.0;
+        if (on)
+            for (int d = lane; d < D; d += 64) {
+                const size_t k = ((size_t)m * S + s) * D + d;
+                const double var = fmax(md.covars[k], 2.2250738585072014e-308);
+                acc += log(var) + md.means[k] * md.means[k] / var;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) cst[col] = on ? -0.5 * (acc + D * 1.8378770664093453) * kLog2e : kNegBig;
+    }
+}
+
+__device__ __forceinline__ double xchg16(double v) { return __shfl_xor(v, 16, 64); }
+
+template <int SP, int R>
+__global__ __launch_bounds__(256) void score_f64_kernel(
+    const double* __restrict__ X, const int64_t* __restrict__ off, int64_t U, int64_t n_frames,
+    srx_models_t md, F64Tables tb, double* __restrict__ out) {
+    constexpr int KQ = 4 * R;
+    const int M = md.n_models, S = md.n_states, D = md.n_features;
+    const int lane = threadIdx.x & 63, g = lane >> 4, ul = lane & 15;
+    const int tile = blockIdx.y;
+    const int64_t group = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (group * 16 >= U) return;
+    const int64_t u = group * 16 + ul;
+    const bool valid = u < U;
+    const int64_t uc = valid ? u : U - 1;
+    int64_t f0 = off[uc];
+    const int T = valid ? (int)(off[uc + 1] - f0) : 0;
+    if (f0 > n_frames - 1) f0 = n_frames - 1;   // empty trailing utterance: stay in bounds
+    int Tmax = T;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o, 64));
+
+    // ---- loop-invariant registers: this lane's A operands (row ul of the tile) ...
+    const int acol = tile * 16 + 4 * (ul & 3) + (ul >> 2);
+    double w[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) w[q] = tb.W[((size_t)acol * KQ + q) * 4 + g];
+    // ... and, for its own four result rows (logical columns 4g .. 4g+3), the constants,
+    // start probabilities and transition coefficients
+    const int m = SP == 4 ? 4 * tile + g : 2 * tile + (g >> 1);
+    const int h = SP == 4 ? 0 : (g & 1);
+    constexpr int NI = SP == 4 ? 4 : 8;         // source states per model
+    f64x4 c0;
+    double pi_[4], a[NI][4];                    // a[i][r]: from source i to own state r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        c0[r] = tb.cst[tile * 16 + 4 * g + r];
+        const int j = 4 * h + r;
+        pi_[r] = (m < M && j < S) ? md.startprob[m * S + j] : 0.0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            // i < 4: states held by this lane, i >= 4: states held by the partner lane
+            const int src = SP == 4 ? i : (i < 4 ? 4 * h + i : 4 * (1 - h) + (i - 4));
+            a[i][r] = (m < M && j < S && src < S) ? md.transmat[((size_t)m * S + src) * S + j] : 0.0;
+        }
+    }
+
+    double alpha[4] = {0.0, 0.0, 0.0, 0.0};
+    double lp = 0.0;
+
+    // ---- frame loads: two adjacent values per r
+    const double* xbase = X + f0 * D;
+    double xc[R][2], xn[R][2];
+    auto load = [&](int t, double (&dst)[R][2]) {
+        int tc = t < T ? t : T - 1;
+        if (tc < 0) tc = 0;
+        const double* p = xbase + (int64_t)tc * D;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            // features past D meet zero weights: read a valid neighbour instead
+            dst[r][0] = p[min(8 * r + 2 * g, D - 1)];
+            dst[r][1] = p[min(8 * r + 2 * g + 1, D - 1)];
+        }
+    };
+    if (Tmax > 0) load(0, xc);
+
+    for (int t = 0; t < Tmax; ++t) {
+        if (t + 1 < Tmax) load(t + 1, xn);
+        f64x4 acc = c0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double x0 = xc[r][0], x1 = xc[r][1];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w[4 * r + 0], x0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w[4 * r + 1], x1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w[4 * r + 2], x0 * x0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w[4 * r + 3], x1 * x1, acc, 0, 0, 0);
+        }
+        // shift by the frame's largest log-density over the model's states
+        double mx = fmax(fmax(acc[0], acc[1]), fmax(acc[2], acc[3]));
+        if (SP == 8) mx = fmax(mx, xchg16(mx));
+        double b[4], na[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[r] = exp2(acc[r] - mx);
+        if (t == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) na[r] = pi_[r] * b[r];
+        } else {
+            double pa[4];
+            if (SP == 8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pa[i] = xchg16(alpha[i]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s = fma(alpha[i], a[i][r], s);
+                if (SP == 8) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s = fma(pa[i], a[4 + i][r], s);
+                }
+                na[r] = s * b[r];
+            }
+        }
+        double c = (na[0] + na[1]) + (na[2] + na[3]);
+        if (SP == 8) c += xchg16(c);
+        // a chain no state can continue (c == 0) stays at zero; its log-probability is -inf
+        const double ci = c > 0.0 ? 1.0 / c : 0.0;
+        const double dl = mx + log2(c);
+        if (t < T) {
+            lp += dl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) alpha[r] = na[r] * ci;
+        }
+        if (t + 1 < Tmax) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                xc[r][0] = xn[r][0];
+                xc[r][1] = xn[r][1];
+            }
+        }
+    }
+
+    const bool writer = SP == 4 ? true : (g & 1) == 0;
+    if (valid && writer && m < M) out[u * M + m] = lp * kLn2;
+}
+
+template <int SP, int R>
+void launch(const double* X, const int64_t* off, int64_t U, int64_t n_frames, const srx_models_t& md,
+            int n_tiles, F64Tables tb, double* out, hipStream_t st) {
+    const int64_t groups = (U + 15) / 16;
+    const unsigned grid = (unsigned)((groups + 3) / 4);
+    hipLaunchKernelGGL((score_f64_kernel<SP, R>), dim3(grid, (unsigned)n_tiles), dim3(256), 0, st, X, off,
+                       U, n_frames, md, tb, out);
+}
+
+}  // namespace
+
+// Models of <= 8 states and <= 48 features; anything else: SRX_EUNSUPPORTED (the caller
+// takes the shape-generic kernels).
+int srx_mfma_score_f64(srx_context* h, const void* X, const int64_t* off, int64_t U,
+                       int64_t n_frames, const srx_models_t* md, double* out, hipStream_t st) {
+    const int M = md->n_models, S = md->n_states, D = md->n_features;
+    if (S > 8 || D > 48 || D < 1 || n_frames <= 0 || U <= 0) return SRX_EUNSUPPORTED;
+    const int SP = S <= 4 ? 4 : 8;
+    const int n_tiles = (M * SP + 15) / 16;
+    if (n_tiles > 65535) return SRX_EUNSUPPORTED;
+    const int R = (D + 7) / 8;
+    const int KQ = 4 * R;
+    const size_t n_w = (size_t)n_tiles * 16 * KQ * 4, n_c = (size_t)n_tiles * 16;
+    double* base;
+    int rc = srx_ws_ensure(h, WS_PARAMS, sizeof(double) * (n_w + n_c), (void**)&base);
+    if (rc) return rc;
+    F64Tables tb;
+    tb.W = base;
+    tb.cst = base + n_w;
+    hipLaunchKernelGGL(f64_prep_kernel, dim3(16), dim3(256), 0, st, *md, SP, n_tiles, R, base, base + n_w);
+    const double* Xd = (const double*)X;
+#define SRX_CASE(sp, r)                                                   \
+    if (SP == sp && R == r) {                                             \
+        launch<sp, r>(Xd, off, U, n_frames, *md, n_tiles, tb, out, st);   \
+        SRX_HIP(hipGetLastError());                                       \
+        return SRX_OK;                                                    \
+    }
+    SRX_CASE(8, 1) SRX_CASE(8, 2) SRX_CASE(8, 3) SRX_CASE(8, 4) SRX_CASE(8, 5) SRX_CASE(8, 6)
+    SRX_CASE(4, 1) SRX_CASE(4, 2) SRX_CASE(4, 3) SRX_CASE(4, 4) SRX_CASE(4, 5) SRX_CASE(4, 6)
+#undef SRX_CASE
+    return SRX_EUNSUPPORTED;
+}

@@ -126,6 +126,11 @@ int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
                    int64_t n_frames, const srx_models_t* models, double* out,
                    hipStream_t st);
 
+// Implemented in score_f64.hip: float64 scoring on the f64 matrix instruction (<= 8 states,
+// <= 48 features), else SRX_EUNSUPPORTED.
+int srx_mfma_score_f64(srx_context* h, const void* X, const int64_t* off, int64_t U,
+                       int64_t n_frames, const srx_models_t* models, double* out, hipStream_t st);
+
 // Implemented in large_model.hip.
 int srx_large_gmm_emission(srx_context* h, const void* X, int dtype, int64_t n_frames,
                            const srx_gmm_t* gm, void* out, hipStream_t st);

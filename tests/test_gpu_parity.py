@@ -647,6 +647,43 @@ def test_random_shapes_against_oracle():
     assert "60 cases ok" in r.stdout
 
 
+def test_random_shapes_against_oracle_float64():
+    """The same fuzzer in float64, 60 seeded cases (states up to 40, features up to 69): models
+    of up to 8 states and 48 features score on the f64 matrix-core kernel, the rest on the
+    shape-generic kernels; tolerances 1e-10 relative on log-probabilities."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_shapes.py"), "60", "9", "float64"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "60 cases ok" in r.stdout
+
+
+@pytest.mark.parametrize("M,S,D", [(1, 1, 1), (5, 4, 9), (7, 3, 48), (3, 8, 40), (9, 7, 17), (33, 2, 5)])
+def test_float64_matrix_core_scoring_equals_generic(sra, ctx, M, S, D):
+    """srx_forward_score in float64 (f64 matrix instruction) against the shape-generic
+    float64 kernel on ragged batches with empty and one-frame utterances, banks that end
+    inside a tile and banks of many tiles: 1e-12 relative."""
+    rng = np.random.default_rng(100 * M + 10 * S + D)
+    prms = [ho.random_params(rng, S, D) for _ in range(M)]
+    lengths = np.array([0, 1, 2, 37, 0, 120, 5, 64, 1, 0, 33, 16, 17, 250, 3, 8, 9, 0], dtype=np.int64)
+    X = rng.standard_normal((int(lengths.sum()), D))
+    bank = _bank(sra, ctx, prms)
+    data = sra.Ragged(ctx, X, lengths, dtype="float64")
+    fast = bank.score(data).cpu().numpy()
+    gen = bank.score(data, generic=True).cpu().numpy()
+    assert fast.shape == (len(lengths), M)
+    live = lengths > 0
+    np.testing.assert_allclose(fast[live], gen[live], rtol=1e-12, atol=1e-12)
+    np.testing.assert_array_equal(fast[~live], gen[~live])
+    for k in (3, 13):                                   # and against the oracle itself
+        x = X[lengths[:k].sum():lengths[:k + 1].sum()]
+        for mi in (0, M - 1):
+            np.testing.assert_allclose(fast[k, mi], ho.score(prms[mi], x, loops=False), rtol=1e-11)
+
+
 def test_random_front_end_configurations_against_oracle():
     """tools/fuzz_mfcc.py, 80 seeded cases: random sample rates, frame lengths, 512 / 1024
     point transforms, 8..64 filters, 3..16 cepstra, delta orders 0..2 with half-widths 1..3,
