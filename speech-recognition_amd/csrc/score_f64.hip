@@ -7,13 +7,13 @@
 // Emission as a contraction, per frame x and state column c (log2 units throughout):
 //     ll2[c] = cst[c] + sum_d  x_d * (mu/var * log2e) + x_d^2 * (-1/(2 var) * log2e)
 // Wave geometry: one wave scores 16 utterances against ONE tile of 16 state columns
-// (4 models of <= 4 states or 2 models of <= 8 states), time step by time step; the
+// (4 models of <= 4 states, 2 models of <= 8 or 1 model of <= 16), time step by time step; the
 // tiles of a bank are the grid's y axis and each re-reads X.  Matrix columns are
 // utterances.  The f64 instruction spreads its 16 result rows differently from the f32
 // one: register r of lane group g (= lane / 16) is row 4r + g.  State columns are
 // therefore placed so that row 4r + g is "logical column" 4g + r = (model 4g/SP, state
-// (4g + r) mod SP): a lane then holds four consecutive states of one model, and a model
-// of 8 states sits in lanes l and l ^ 16, as in the float32 kernels.  The A operand of
+// (4g + r) mod SP): a lane then holds four consecutive states of one model; a model of 8
+// states sits in lanes l and l ^ 16, one of 16 in all four lane groups of an utterance.  The A operand of
 // lane (g, ul) is the weight of row ul, i.e. of logical column 4 (ul & 3) + (ul >> 2).
 // The B operand of k-step q comes from lane group g: q = 4r + e is feature
 // d = 8r + 2g + (e & 1), x_d for e < 2 and x_d^2 for e >= 2.
@@ -68,8 +68,6 @@ __global__ void f64_prep_kernel(srx_models_t md, int SP, int n_tiles, int R, dou
     }
 }
 
-__device__ __forceinline__ double xchg16(double v) { return __shfl_xor(v, 16, 64); }
-
 template <int SP, int R>
 __global__ __launch_bounds__(256) void score_f64_kernel(
     const double* __restrict__ X, const int64_t* __restrict__ off, int64_t U, int64_t n_frames,
@@ -97,9 +95,10 @@ __global__ __launch_bounds__(256) void score_f64_kernel(
     for (int q = 0; q < KQ; ++q) w[q] = tb.W[((size_t)acol * KQ + q) * 4 + g];
     // ... and, for its own four result rows (logical columns 4g .. 4g+3), the constants,
     // start probabilities and transition coefficients
-    const int m = SP == 4 ? 4 * tile + g : 2 * tile + (g >> 1);
-    const int h = SP == 4 ? 0 : (g & 1);
-    constexpr int NI = SP == 4 ? 4 : 8;         // source states per model
+    constexpr int NB = SP / 4;                  // lane groups (blocks of 4 states) per model
+    const int m = (16 / SP) * tile + g / NB;
+    const int h = g % NB;                       // this lane's block inside its model
+    constexpr int NI = SP;                      // source states per model
     f64x4 c0;
     double pi_[4], a[NI][4];                    // a[i][r]: from source i to own state r
 #pragma unroll
@@ -109,11 +108,22 @@ __global__ __launch_bounds__(256) void score_f64_kernel(
         pi_[r] = (m < M && j < S) ? md.startprob[m * S + j] : 0.0;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            // i < 4: states held by this lane, i >= 4: states held by the partner lane
-            const int src = SP == 4 ? i : (i < 4 ? 4 * h + i : 4 * (1 - h) + (i - 4));
+            // sources 4k .. 4k+3 of the list are the states held by lane l ^ 16k (k = 0: own)
+            const int src = 4 * (h ^ (i >> 2)) + (i & 3);
             a[i][r] = (m < M && j < S && src < S) ? md.transmat[((size_t)m * S + src) * S + j] : 0.0;
         }
     }
+    // sum / maximum over the lane groups of a model
+    auto model_max = [&](double v) {
+        if (SP >= 8) v = fmax(v, __shfl_xor(v, 16, 64));
+        if (SP == 16) v = fmax(v, __shfl_xor(v, 32, 64));
+        return v;
+    };
+    auto model_sum = [&](double v) {
+        if (SP >= 8) v += __shfl_xor(v, 16, 64);
+        if (SP == 16) v += __shfl_xor(v, 32, 64);
+        return v;
+    };
 
     double alpha[4] = {0.0, 0.0, 0.0, 0.0};
     double lp = 0.0;
@@ -146,8 +156,7 @@ __global__ __launch_bounds__(256) void score_f64_kernel(
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w[4 * r + 3], x1 * x1, acc, 0, 0, 0);
         }
         // shift by the frame's largest log-density over the model's states
-        double mx = fmax(fmax(acc[0], acc[1]), fmax(acc[2], acc[3]));
-        if (SP == 8) mx = fmax(mx, xchg16(mx));
+        const double mx = model_max(fmax(fmax(acc[0], acc[1]), fmax(acc[2], acc[3])));
         double b[4], na[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) b[r] = exp2(acc[r] - mx);
@@ -155,25 +164,22 @@ __global__ __launch_bounds__(256) void score_f64_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) na[r] = pi_[r] * b[r];
         } else {
-            double pa[4];
-            if (SP == 8) {
+            double src[NI];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) pa[i] = xchg16(alpha[i]);
-            }
+            for (int i = 0; i < 4; ++i) src[i] = alpha[i];
+#pragma unroll
+            for (int k = 1; k < NB; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) src[4 * k + i] = __shfl_xor(alpha[i], 16 * k, 64);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 double s = 0.0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s = fma(alpha[i], a[i][r], s);
-                if (SP == 8) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) s = fma(pa[i], a[4 + i][r], s);
-                }
+                for (int i = 0; i < NI; ++i) s = fma(src[i], a[i][r], s);
                 na[r] = s * b[r];
             }
         }
-        double c = (na[0] + na[1]) + (na[2] + na[3]);
-        if (SP == 8) c += xchg16(c);
+        const double c = model_sum((na[0] + na[1]) + (na[2] + na[3]));
         // a chain no state can continue (c == 0) stays at zero; its log-probability is -inf
         const double ci = c > 0.0 ? 1.0 / c : 0.0;
         const double dl = mx + log2(c);
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256) void score_f64_kernel(
         }
     }
 
-    const bool writer = SP == 4 ? true : (g & 1) == 0;
+    const bool writer = h == 0;
     if (valid && writer && m < M) out[u * M + m] = lp * kLn2;
 }
 
@@ -206,13 +212,13 @@ void launch(const double* X, const int64_t* off, int64_t U, int64_t n_frames, co
 
 }  // namespace
 
-// Models of <= 8 states and <= 48 features; anything else: SRX_EUNSUPPORTED (the caller
+// Models of <= 16 states and <= 48 features; anything else: SRX_EUNSUPPORTED (the caller
 // takes the shape-generic kernels).
 int srx_mfma_score_f64(srx_context* h, const void* X, const int64_t* off, int64_t U,
                        int64_t n_frames, const srx_models_t* md, double* out, hipStream_t st) {
     const int M = md->n_models, S = md->n_states, D = md->n_features;
-    if (S > 8 || D > 48 || D < 1 || n_frames <= 0 || U <= 0) return SRX_EUNSUPPORTED;
-    const int SP = S <= 4 ? 4 : 8;
+    if (S > 16 || D > 48 || D < 1 || n_frames <= 0 || U <= 0) return SRX_EUNSUPPORTED;
+    const int SP = S <= 4 ? 4 : (S <= 8 ? 8 : 16);
     const int n_tiles = (M * SP + 15) / 16;
     if (n_tiles > 65535) return SRX_EUNSUPPORTED;
     const int R = (D + 7) / 8;
@@ -234,6 +240,7 @@ int srx_mfma_score_f64(srx_context* h, const void* X, const int64_t* off, int64_
     }
     SRX_CASE(8, 1) SRX_CASE(8, 2) SRX_CASE(8, 3) SRX_CASE(8, 4) SRX_CASE(8, 5) SRX_CASE(8, 6)
     SRX_CASE(4, 1) SRX_CASE(4, 2) SRX_CASE(4, 3) SRX_CASE(4, 4) SRX_CASE(4, 5) SRX_CASE(4, 6)
+    SRX_CASE(16, 1) SRX_CASE(16, 2) SRX_CASE(16, 3) SRX_CASE(16, 4) SRX_CASE(16, 5) SRX_CASE(16, 6)
 #undef SRX_CASE
     return SRX_EUNSUPPORTED;
 }

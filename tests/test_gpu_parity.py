@@ -649,7 +649,7 @@ def test_random_shapes_against_oracle():
 
 def test_random_shapes_against_oracle_float64():
     """The same fuzzer in float64, 60 seeded cases (states up to 40, features up to 69): models
-    of up to 8 states and 48 features score on the f64 matrix-core kernel, the rest on the
+    of up to 16 states and 48 features score on the f64 matrix-core kernel, the rest on the
     shape-generic kernels; tolerances 1e-10 relative on log-probabilities."""
     import os
     import subprocess
@@ -661,7 +661,8 @@ def test_random_shapes_against_oracle_float64():
     assert "60 cases ok" in r.stdout
 
 
-@pytest.mark.parametrize("M,S,D", [(1, 1, 1), (5, 4, 9), (7, 3, 48), (3, 8, 40), (9, 7, 17), (33, 2, 5)])
+@pytest.mark.parametrize("M,S,D", [(1, 1, 1), (5, 4, 9), (7, 3, 48), (3, 8, 40), (9, 7, 17), (33, 2, 5),
+                                   (2, 16, 39), (3, 9, 13), (5, 13, 48)])
 def test_float64_matrix_core_scoring_equals_generic(sra, ctx, M, S, D):
     """srx_forward_score in float64 (f64 matrix instruction) against the shape-generic
     float64 kernel on ragged batches with empty and one-frame utterances, banks that end

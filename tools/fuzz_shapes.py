@@ -1,6 +1,6 @@
 """Random model / batch shapes through the float32 fast paths against the numpy oracle:
 python tools/fuzz_shapes.py [n_cases] [seed] [float32|float64].  Prints the first failure
-and exits 1.  float64 runs the f64 matrix-core scoring kernel (up to 8 states, 48 features) and the
+and exits 1.  float64 runs the f64 matrix-core scoring kernel (up to 16 states, 48 features) and the
 shape-generic kernels (states up to 40) with tolerances a million times tighter."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
