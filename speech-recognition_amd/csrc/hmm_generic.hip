@@ -367,6 +367,8 @@ __global__ void reduce_stats_kernel(const double* __restrict__ part_fb, int n_fb
     for (int i = tid; i < M * P; i += nth) {
         const int m = i / P, r = i % P;
         double s = 0.0;
+        // (fixed order of additions; unrolled so that eight loads are in flight)
+#pragma unroll 8
         for (int b = 0; b < n_fb; ++b) s += part_fb[(size_t)b * M * P + i];
         int64_t dst;
         if (r < S * S) dst = L.trans + r;
@@ -378,6 +380,7 @@ __global__ void reduce_stats_kernel(const double* __restrict__ part_fb, int n_fb
     for (int i = tid; i < M * Q; i += nth) {
         const int m = i / Q, r = i % Q;
         double s = 0.0;
+#pragma unroll 8
         for (int b = 0; b < n_obs; ++b) s += part_obs[(size_t)b * M * Q + i];
         const int64_t dst = r < S ? L.post + r : L.obs + (r - S);  // obs2 follows obs
         out[(size_t)m * L.size + dst] = s;
@@ -877,6 +880,11 @@ int viterbi_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int6
         if (rc == SRX_OK) done = true;
         else if (rc != SRX_EUNSUPPORTED) return rc;
     }
+    if constexpr (std::is_same<T, double>::value) {
+        rc = srx_mfma_emission_utt_f64(h, X, off, U, n_frames, utt_model, md, (double*)ll, st);
+        if (rc == SRX_OK) done = true;
+        else if (rc != SRX_EUNSUPPORTED) return rc;
+    }
     if (!done)
         hipLaunchKernelGGL(emission_kernel<T>, dim3(grid_for(h, U, 1)), dim3(kBlock), 0, st,
                            (const T*)X, off, U, utt_model, 0, M, S, D, tb, ll);
@@ -926,6 +934,11 @@ int posteriors_t(srx_context* h, const void* X, const int64_t* off, int64_t U, i
     bool done = false;
     if constexpr (std::is_same<T, float>::value) {
         rc = srx_mfma_emission_utt_f32(h, X, off, U, n_frames, utt_model, md, (float*)ll, st);
+        if (rc == SRX_OK) done = true;
+        else if (rc != SRX_EUNSUPPORTED) return rc;
+    }
+    if constexpr (std::is_same<T, double>::value) {
+        rc = srx_mfma_emission_utt_f64(h, X, off, U, n_frames, utt_model, md, (double*)ll, st);
         if (rc == SRX_OK) done = true;
         else if (rc != SRX_EUNSUPPORTED) return rc;
     }
@@ -984,8 +997,16 @@ int estep_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_
     size_t lds = sizeof(double) * (size_t)M * P;
     const int acc_in_lds = lds <= 64 * 1024;
     if (!acc_in_lds) lds = 0;
-    hipLaunchKernelGGL(emission_kernel<T>, dim3(grid_for(h, U, 1)), dim3(kBlock), 0, st,
-                       (const T*)X, off, U, utt_model, 0, M, S, D, tb, ll);
+    bool emitted = false;
+    if constexpr (std::is_same<T, double>::value) {
+        // matrix-core emission where the shape allows it
+        rc = srx_mfma_emission_utt_f64(h, X, off, U, n_frames, utt_model, md, (double*)ll, st);
+        if (rc == SRX_OK) emitted = true;
+        else if (rc != SRX_EUNSUPPORTED) return rc;
+    }
+    if (!emitted)
+        hipLaunchKernelGGL(emission_kernel<T>, dim3(grid_for(h, U, 1)), dim3(kBlock), 0, st,
+                           (const T*)X, off, U, utt_model, 0, M, S, D, tb, ll);
     SP_DISPATCH(sp, hipLaunchKernelGGL((fb_chain_kernel<T, SP>), dim3(g_fb), dim3(kBlock), lds, st,
                                        (const T*)ll, off, U, utt_model, utt_order, M, S, tb, lat,
                                        sc, part, (double*)nullptr, acc_in_lds));
@@ -1000,7 +1021,10 @@ int estep_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_
     else if (slots <= 8) OBS(8);
     else OBS(16);
 #undef OBS
-    hipLaunchKernelGGL(reduce_stats_kernel, dim3(8), dim3(kBlock), 0, st, (const double*)part, g_fb,
+    // one thread per output sum
+    const int64_t n_out = (int64_t)M * (P > Q ? P : Q);
+    const int g_red = (int)std::min<int64_t>((n_out + kBlock - 1) / kBlock, 4096);
+    hipLaunchKernelGGL(reduce_stats_kernel, dim3(g_red), dim3(kBlock), 0, st, (const double*)part, g_fb,
                        (const double*)part_obs, g_obs, M, S, D, out_stats);
     SRX_HIP(hipGetLastError());
     return SRX_OK;

@@ -201,6 +201,123 @@ __global__ __launch_bounds__(256) void score_f64_kernel(
     if (valid && writer && m < M) out[u * M + m] = lp * kLn2;
 }
 
+// ---------------------------------------------------------------------------
+// Stand-alone float64 emission log-densities (natural log) of each utterance under its
+// own model, [n_frames, S], for the float64 Viterbi / posteriors / E-step chains.  A wave
+// takes an utterance, 16 CONSECUTIVE frames as the matrix columns, the model's states as
+// one 16-row tile.  Lane group g supplies features 8q + 2g, 8q + 2g + 1 of a frame (one
+// 16-byte load per q); weight table per model
+//   W[row][q][x | x^2][g][i] = coefficient of feature 8q + 2g + i.
+// Result register r of lane (g, frame) is state 4r + g.
+__global__ void emission_f64_prep_kernel(srx_models_t md, int RQ, double* W, double* cst) {
+    const int M = md.n_models, S = md.n_states, D = md.n_features;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    const int per_row = RQ * 16;
+    for (int i = tid; i < M * 16 * per_row; i += nth) {
+        const int row = i / per_row, w = i % per_row;
+        const int q = w >> 4, e = (w >> 3) & 1, d = 8 * q + (w & 7);
+        const int m = row >> 4, s_ = row & 15;
+        double v = 0.0;
+        if (s_ < S && d < D) {
+            const size_t k = ((size_t)m * S + s_) * D + d;
+            const double var = fmax(md.covars[k], 2.2250738585072014e-308);
+            v = e ? -0.5 / var : md.means[k] / var;
+        }
+        W[i] = v;
+    }
+    const int wave = tid >> 6, lane = tid & 63, n_wave = nth >> 6;
+    for (int row = wave; row < M * 16; row += n_wave) {
+        const int m = row >> 4, s_ = row & 15;
+        double acc = 0.0;
+        if (s_ < S)
+            for (int d = lane; d < D; d += 64) {
+                const size_t k = ((size_t)m * S + s_) * D + d;
+                const double var = fmax(md.covars[k], 2.2250738585072014e-308);
+                acc += log(var) + md.means[k] * md.means[k] / var;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) cst[row] = s_ < S ? -0.5 * (acc + D * 1.8378770664093453) : 0.0;
+    }
+}
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int RQ>
+__global__ __launch_bounds__(256) void emission_utt_f64_kernel(
+    const double* __restrict__ X, const int64_t* __restrict__ off, int64_t U, int64_t n_frames,
+    const int32_t* __restrict__ utt_model, int S, int D, const double* __restrict__ W,
+    const double* __restrict__ cst, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, ul = lane & 15;
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const unsigned lane_off = (unsigned)ul * (unsigned)D * 8u + 16u * g;
+    int cur = -1;
+    f64x2 w1[RQ], w2[RQ];
+    f64x4 c0 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) w1[q] = w2[q] = f64x2{0.0, 0.0};
+    for (int64_t u = wid; u < U; u += n_waves) {
+        const int m = utt_model ? utt_model[u] : 0;
+        const int64_t f0 = off[u];
+        const int64_t T = off[u + 1] - f0;
+        if (T <= 0) continue;
+        if (m != cur) {
+            cur = m;
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const double* p = W + (((size_t)(m * 16 + ul)) * RQ + q) * 16 + 2 * g;
+                w1[q] = *(const f64x2*)p;
+                w2[q] = *(const f64x2*)(p + 8);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c0[r] = cst[m * 16 + 4 * r + g];
+        }
+        const int64_t n_groups = (T + 15) / 16;
+        auto load = [&](int64_t k, u32x4 (&dst)[RQ]) {
+            // descriptor over [first frame of the group, end of the utterance): rows past
+            // the end read as zeros
+            const int64_t fk = k < n_groups ? f0 + k * 16 : f0;
+            const int64_t rest = k < n_groups ? (f0 + T - fk) * (int64_t)D * 8 : 0;
+            const uintptr_t a = (uintptr_t)(X + fk * D);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+            const unsigned n = (unsigned)(rest < 0xFFFFFF00ll ? rest : 0xFFFFFF00ll);
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
+#pragma unroll
+            for (int q = 0; q < RQ; ++q)
+                dst[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off + 64u * q, 0, 0);
+        };
+        u32x4 xa[RQ], xb[RQ];
+        load(0, xa);
+        for (int64_t k = 0; k < n_groups; ++k) {
+            load(k + 1, xb);
+            f64x4 a1 = c0, a2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const f64x2 x = __builtin_bit_cast(f64x2, xa[q]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w1[q][i], x[i], a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[q][i], x[i] * x[i], a2, 0, 0, 0);
+                }
+            }
+            const int64_t t = k * 16 + ul;
+            if (t < T) {
+                double* o = out + (f0 + t) * S;
+                const f64x4 v = a1 + a2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * r + g < S) o[4 * r + g] = v[r];
+            }
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) xa[q] = xb[q];
+        }
+    }
+}
+
 template <int SP, int R>
 void launch(const double* X, const int64_t* off, int64_t U, int64_t n_frames, const srx_models_t& md,
             int n_tiles, F64Tables tb, double* out, hipStream_t st) {
@@ -241,6 +358,36 @@ int srx_mfma_score_f64(srx_context* h, const void* X, const int64_t* off, int64_
     SRX_CASE(8, 1) SRX_CASE(8, 2) SRX_CASE(8, 3) SRX_CASE(8, 4) SRX_CASE(8, 5) SRX_CASE(8, 6)
     SRX_CASE(4, 1) SRX_CASE(4, 2) SRX_CASE(4, 3) SRX_CASE(4, 4) SRX_CASE(4, 5) SRX_CASE(4, 6)
     SRX_CASE(16, 1) SRX_CASE(16, 2) SRX_CASE(16, 3) SRX_CASE(16, 4) SRX_CASE(16, 5) SRX_CASE(16, 6)
+#undef SRX_CASE
+    return SRX_EUNSUPPORTED;
+}
+
+// Float64 log-densities of every utterance under its own model, out[frame][state]
+// (<= 16 states, <= 48 features, one utterance < 4 GiB); its tables live in the WS_MISC slot.
+int srx_mfma_emission_utt_f64(srx_context* h, const void* X, const int64_t* off, int64_t U,
+                              int64_t n_frames, const int32_t* utt_model, const srx_models_t* md,
+                              double* out, hipStream_t st) {
+    const int M = md->n_models, S = md->n_states, D = md->n_features;
+    if (S > 16 || D > 48 || M > 4096 || n_frames <= 0 || U <= 0) return SRX_EUNSUPPORTED;
+    const int RQ = (D + 7) / 8;
+    const size_t n_w = (size_t)M * 16 * RQ * 16, n_c = (size_t)M * 16;
+    double* base;
+    int rc = srx_ws_ensure(h, WS_MISC, sizeof(double) * (n_w + n_c), (void**)&base);
+    if (rc) return rc;
+    double* cst = base + n_w;
+    hipLaunchKernelGGL(emission_f64_prep_kernel, dim3(16), dim3(256), 0, st, *md, RQ, base, cst);
+    int64_t gx = (U + 3) / 4;
+    const int64_t cap = (int64_t)h->n_cu * 8;
+    if (gx > cap) gx = cap;
+    const double* Xd = (const double*)X;
+#define SRX_CASE(rq)                                                                        \
+    if (RQ == rq) {                                                                         \
+        hipLaunchKernelGGL((emission_utt_f64_kernel<rq>), dim3((unsigned)gx), dim3(256), 0, \
+                           st, Xd, off, U, n_frames, utt_model, S, D, base, cst, out);      \
+        SRX_HIP(hipGetLastError());                                                         \
+        return SRX_OK;                                                                      \
+    }
+    SRX_CASE(6) SRX_CASE(5) SRX_CASE(4) SRX_CASE(3) SRX_CASE(2) SRX_CASE(1)
 #undef SRX_CASE
     return SRX_EUNSUPPORTED;
 }

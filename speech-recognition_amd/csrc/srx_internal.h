@@ -131,6 +131,12 @@ int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
 int srx_mfma_score_f64(srx_context* h, const void* X, const int64_t* off, int64_t U,
                        int64_t n_frames, const srx_models_t* models, double* out, hipStream_t st);
 
+// Float64 log-densities of each utterance under its own model on the f64 matrix
+// instruction, out[frame][state] (<= 16 states, <= 48 features), else SRX_EUNSUPPORTED.
+int srx_mfma_emission_utt_f64(srx_context* h, const void* X, const int64_t* off, int64_t U,
+                              int64_t n_frames, const int32_t* utt_model, const srx_models_t* md,
+                              double* out, hipStream_t st);
+
 // Implemented in large_model.hip.
 int srx_large_gmm_emission(srx_context* h, const void* X, int dtype, int64_t n_frames,
                            const srx_gmm_t* gm, void* out, hipStream_t st);
