@@ -989,6 +989,9 @@ int estep_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_
     const int g_fb = grid_for(h, U, kBlock / sp);
     int g_obs = grid_for(h, U, 4);
     if (g_obs > 1024) g_obs = 1024;
+    // float64 on the matrix cores: one-wave workgroups, so twice as many slices
+    const bool obs_mfma = std::is_same<T, double>::value && S <= 16 && D <= 48;
+    if (obs_mfma) g_obs = (int)std::min<int64_t>(U, 2048);
     double* part;
     rc = srx_ws_ensure(h, WS_PARTIAL, sizeof(double) * ((size_t)g_fb * M * P + (size_t)g_obs * M * Q),
                        (void**)&part);
@@ -1015,7 +1018,10 @@ int estep_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_
 #define OBS(SL)                                                                                   \
     hipLaunchKernelGGL((obs_stats_kernel<T, SL>), dim3(g_obs), dim3(kBlock), 0, st, (const T*)X,  \
                        (const T*)lat, off, U, utt_model, utt_order, M, S, D, part_obs)
-    if (slots <= 1) OBS(1);
+    if (obs_mfma) {
+        rc = srx_mfma_obs_stats_f64(h, X, lat, off, U, utt_model, utt_order, md, part_obs, g_obs, st);
+        if (rc) return rc;
+    } else if (slots <= 1) OBS(1);
     else if (slots <= 2) OBS(2);
     else if (slots <= 4) OBS(4);
     else if (slots <= 8) OBS(8);

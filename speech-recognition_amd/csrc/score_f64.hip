@@ -318,6 +318,90 @@ __global__ __launch_bounds__(256) void emission_utt_f64_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Observation sums of the float64 E-step (accumulate_sufficient_statistics,
+// my_hmmlearn/hmm.py:237-253): post += sum_t gamma_t, obs += gamma^T X, obs**2 += gamma^T X^2
+// as matrix products.  One wave per workgroup walks a contiguous slice of the processing
+// order; four frames are one k-step: A[row = state][k] = gamma[t0 + k][state],
+// B[k][col] = x[t0 + k][16c + col] (and its square) for NC blocks of 16 features, so result
+// register r of lane (g, col) is the sum for state 4r + g and feature 16c + col.  The sums
+// stay in registers while the model does not change, then go to the wave's own slice of
+// `partial` [gridDim][M][S + 2 S D] (layout and fixed-order reduction of obs_stats_kernel).
+template <int NC>
+__global__ __launch_bounds__(64) void obs_stats_f64_kernel(
+    const double* __restrict__ X, const double* __restrict__ gamma, const int64_t* __restrict__ off,
+    int64_t U, const int32_t* __restrict__ utt_model, const int64_t* __restrict__ utt_order, int M,
+    int S, int D, double* __restrict__ partial) {
+    const int lane = threadIdx.x, g = lane >> 4, ul = lane & 15;
+    const int SD = S * D, Q = S + 2 * SD;
+    double* mine = partial + (size_t)blockIdx.x * M * Q;
+    for (int i = lane; i < M * Q; i += 64) mine[i] = 0.0;
+    const int64_t per = (U + gridDim.x - 1) / gridDim.x;
+    const int64_t k0 = blockIdx.x * per;
+    const int64_t k1 = k0 + per < U ? k0 + per : U;
+    f64x4 o1[NC], o2[NC];
+    double ap = 0.0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) o1[c] = o2[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+    int cur = -1;
+    auto flush = [&](int mm) {
+        if (mm < 0) return;
+        double* dst = mine + (size_t)mm * Q;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int st_ = 4 * r + g, d = 16 * c + ul;
+                if (st_ < S && d < D) {
+                    dst[S + st_ * D + d] += o1[c][r];
+                    dst[S + SD + st_ * D + d] += o2[c][r];
+                }
+            }
+            o1[c] = o2[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+        }
+        double p = ap;
+        p += __shfl_xor(p, 16, 64);
+        p += __shfl_xor(p, 32, 64);
+        if (g == 0 && ul < S) dst[ul] += p;
+        ap = 0.0;
+    };
+    // (the slice is zeroed and later updated by different lanes of this one-wave workgroup)
+    __syncthreads();
+    for (int64_t k = k0; k < k1; ++k) {
+        const int64_t u = utt_order ? utt_order[k] : k;
+        const int m = utt_model ? utt_model[u] : 0;
+        if (m != cur) {
+            flush(cur);
+            cur = m;
+        }
+        const int64_t f0 = off[u], T = off[u + 1] - f0;
+        const bool st_ok = ul < S;
+        auto load = [&](int64_t t0, double& gv, double (&xv)[NC]) {
+            const int64_t t = t0 + g;
+            const bool ok = t < T;
+            const int64_t f = f0 + (ok ? t : 0);
+            gv = ok && st_ok ? gamma[f * S + ul] : 0.0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) xv[c] = ok && 16 * c + ul < D ? X[f * D + 16 * c + ul] : 0.0;
+        };
+        double ga, xa[NC], gb, xb[NC];
+        if (T > 0) load(0, ga, xa);
+        for (int64_t t0 = 0; t0 < T; t0 += 4) {
+            if (t0 + 4 < T) load(t0 + 4, gb, xb);
+            ap += ga;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                o1[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, xa[c], o1[c], 0, 0, 0);
+                o2[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga, xa[c] * xa[c], o2[c], 0, 0, 0);
+            }
+            ga = gb;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) xa[c] = xb[c];
+        }
+    }
+    flush(cur);
+}
+
 template <int SP, int R>
 void launch(const double* X, const int64_t* off, int64_t U, int64_t n_frames, const srx_models_t& md,
             int n_tiles, F64Tables tb, double* out, hipStream_t st) {
@@ -388,6 +472,27 @@ int srx_mfma_emission_utt_f64(srx_context* h, const void* X, const int64_t* off,
         return SRX_OK;                                                                      \
     }
     SRX_CASE(6) SRX_CASE(5) SRX_CASE(4) SRX_CASE(3) SRX_CASE(2) SRX_CASE(1)
+#undef SRX_CASE
+    return SRX_EUNSUPPORTED;
+}
+
+// Observation sums of the float64 E-step into `partial` [n_slices][M][S + 2 S D]
+// (<= 16 states, <= 48 features); n_slices workgroups of one wave.
+int srx_mfma_obs_stats_f64(srx_context* h, const void* X, const void* gamma, const int64_t* off,
+                           int64_t U, const int32_t* utt_model, const int64_t* utt_order,
+                           const srx_models_t* md, double* partial, int n_slices, hipStream_t st) {
+    const int M = md->n_models, S = md->n_states, D = md->n_features;
+    if (S > 16 || D > 48 || U <= 0 || n_slices < 1) return SRX_EUNSUPPORTED;
+    const int NC = (D + 15) / 16;
+#define SRX_CASE(nc)                                                                              \
+    if (NC == nc) {                                                                               \
+        hipLaunchKernelGGL((obs_stats_f64_kernel<nc>), dim3((unsigned)n_slices), dim3(64), 0, st, \
+                           (const double*)X, (const double*)gamma, off, U, utt_model, utt_order,  \
+                           M, S, D, partial);                                                     \
+        SRX_HIP(hipGetLastError());                                                               \
+        return SRX_OK;                                                                            \
+    }
+    SRX_CASE(3) SRX_CASE(2) SRX_CASE(1)
 #undef SRX_CASE
     return SRX_EUNSUPPORTED;
 }
