@@ -990,7 +990,7 @@ int estep_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_
     int g_obs = grid_for(h, U, 4);
     if (g_obs > 1024) g_obs = 1024;
     // float64 on the matrix cores: one-wave workgroups, so twice as many slices
-    const bool obs_mfma = std::is_same<T, double>::value && S <= 16 && D <= 48;
+    const bool obs_mfma = std::is_same<T, double>::value && S <= 16 && D <= 48 && U > 0;
     if (obs_mfma) g_obs = (int)std::min<int64_t>(U, 2048);
     double* part;
     rc = srx_ws_ensure(h, WS_PARTIAL, sizeof(double) * ((size_t)g_fb * M * P + (size_t)g_obs * M * Q),

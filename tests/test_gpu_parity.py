@@ -685,6 +685,22 @@ def test_float64_matrix_core_scoring_equals_generic(sra, ctx, M, S, D):
             np.testing.assert_allclose(fast[k, mi], ho.score(prms[mi], x, loops=False), rtol=1e-11)
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_estep_without_utterances_or_frames(sra, ctx, dtype):
+    """No utterance at all, and utterances that are all empty: the statistics are zeros (the
+    dict of initialize_sufficient_statistics, hmm.py:224-235) in both dtypes."""
+    rng = np.random.default_rng(4)
+    prms = [ho.random_params(rng, 5, 7) for _ in range(3)]
+    bank = _bank(sra, ctx, prms)
+    for lengths in ([], [0, 0, 0]):
+        data = sra.Ragged(ctx, np.zeros((0, 7)), lengths, dtype=dtype)
+        um = np.zeros(len(lengths), dtype=np.int32)
+        st = bank.estep(data, um).cpu().numpy()
+        assert st.shape == (3, bank.stats_size)
+        # every sum is zero, and an utterance without frames is not an observation
+        assert np.all(st == 0.0), (dtype, lengths)
+
+
 def test_random_front_end_configurations_against_oracle():
     """tools/fuzz_mfcc.py, 80 seeded cases: random sample rates, frame lengths, 512 / 1024
     point transforms, 8..64 filters, 3..16 cepstra, delta orders 0..2 with half-widths 1..3,
