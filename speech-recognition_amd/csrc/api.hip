@@ -182,6 +182,9 @@ int srx_emission_loglik(srx_handle_t h, const void* X, int dtype, int64_t n_fram
     if (dtype == SRX_F32) {
         rc = srx_mfma_emission(h, X, n_frames, models, (float*)out, (hipStream_t)stream);
         if (rc != SRX_EUNSUPPORTED) return rc;
+    } else {
+        rc = srx_mfma_emission_f64(h, X, n_frames, models, (double*)out, (hipStream_t)stream);
+        if (rc != SRX_EUNSUPPORTED) return rc;
     }
     return srx_generic_emission(h, X, dtype, n_frames, models, out, (hipStream_t)stream);
 }

@@ -318,6 +318,56 @@ __global__ __launch_bounds__(256) void emission_utt_f64_kernel(
     }
 }
 
+// The same log-densities for EVERY state of EVERY model, out[frame][m * S + s]
+// (srx_emission_loglik in float64): a wave takes groups of 16 consecutive frames
+// (grid-stride), loads them once and walks the models' tiles, whose weights come from the
+// table of emission_f64_prep_kernel through the cache.
+template <int RQ>
+__global__ __launch_bounds__(256) void emission_all_f64_kernel(
+    const double* __restrict__ X, int64_t n_frames, int M, int S, int D,
+    const double* __restrict__ W, const double* __restrict__ cst, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, ul = lane & 15;
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_groups = (n_frames + 15) / 16;
+    const int64_t C = (int64_t)M * S;
+    for (int64_t k = wid; k < n_groups; k += n_waves) {
+        const int64_t t = k * 16 + ul;
+        const bool ok = t < n_frames;
+        const double* row = X + (ok ? t : n_frames - 1) * D;
+        f64x2 x[RQ];
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) {
+            // features past D meet zero weights: read a valid neighbour instead
+            const int d0 = 8 * q + 2 * g;
+            x[q][0] = row[d0 < D ? d0 : D - 1];
+            x[q][1] = row[d0 + 1 < D ? d0 + 1 : D - 1];
+        }
+        for (int m = 0; m < M; ++m) {
+            f64x4 a1, a2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a1[r] = cst[m * 16 + 4 * r + g];
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+                const double* p = W + (((size_t)(m * 16 + ul)) * RQ + q) * 16 + 2 * g;
+                const f64x2 w1 = *(const f64x2*)p, w2 = *(const f64x2*)(p + 8);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w1[i], x[q][i], a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[i], x[q][i] * x[q][i], a2, 0, 0, 0);
+                }
+            }
+            if (ok) {
+                double* o = out + t * C + (int64_t)m * S;
+                const f64x4 v = a1 + a2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * r + g < S) o[4 * r + g] = v[r];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Observation sums of the float64 E-step (accumulate_sufficient_statistics,
 // my_hmmlearn/hmm.py:237-253): post += sum_t gamma_t, obs += gamma^T X, obs**2 += gamma^T X^2
@@ -493,6 +543,34 @@ int srx_mfma_obs_stats_f64(srx_context* h, const void* X, const void* gamma, con
         return SRX_OK;                                                                            \
     }
     SRX_CASE(3) SRX_CASE(2) SRX_CASE(1)
+#undef SRX_CASE
+    return SRX_EUNSUPPORTED;
+}
+
+// Float64 log-densities of all state columns of all models, out[frame][m * S + s]
+// (<= 16 states, <= 48 features); tables in the WS_MISC slot.
+int srx_mfma_emission_f64(srx_context* h, const void* X, int64_t n_frames, const srx_models_t* md,
+                          double* out, hipStream_t st) {
+    const int M = md->n_models, S = md->n_states, D = md->n_features;
+    if (S > 16 || D > 48 || M > 4096 || n_frames <= 0) return SRX_EUNSUPPORTED;
+    const int RQ = (D + 7) / 8;
+    const size_t n_w = (size_t)M * 16 * RQ * 16, n_c = (size_t)M * 16;
+    double* base;
+    int rc = srx_ws_ensure(h, WS_MISC, sizeof(double) * (n_w + n_c), (void**)&base);
+    if (rc) return rc;
+    double* cst = base + n_w;
+    hipLaunchKernelGGL(emission_f64_prep_kernel, dim3(16), dim3(256), 0, st, *md, RQ, base, cst);
+    int64_t gx = ((n_frames + 15) / 16 + 3) / 4;
+    const int64_t cap = (int64_t)h->n_cu * 16;
+    if (gx > cap) gx = cap;
+#define SRX_CASE(rq)                                                                        \
+    if (RQ == rq) {                                                                         \
+        hipLaunchKernelGGL((emission_all_f64_kernel<rq>), dim3((unsigned)gx), dim3(256), 0, \
+                           st, (const double*)X, n_frames, M, S, D, base, cst, out);        \
+        SRX_HIP(hipGetLastError());                                                         \
+        return SRX_OK;                                                                      \
+    }
+    SRX_CASE(6) SRX_CASE(5) SRX_CASE(4) SRX_CASE(3) SRX_CASE(2) SRX_CASE(1)
 #undef SRX_CASE
     return SRX_EUNSUPPORTED;
 }

@@ -137,6 +137,10 @@ int srx_mfma_emission_utt_f64(srx_context* h, const void* X, const int64_t* off,
                               int64_t n_frames, const int32_t* utt_model, const srx_models_t* md,
                               double* out, hipStream_t st);
 
+// The same for all state columns of all models, out[frame][m * S + s].
+int srx_mfma_emission_f64(srx_context* h, const void* X, int64_t n_frames, const srx_models_t* md,
+                          double* out, hipStream_t st);
+
 // Observation sums of the float64 E-step as f64 matrix products into
 // partial[n_slices][M][S + 2 S D] (the layout of the generic kernel), else SRX_EUNSUPPORTED.
 int srx_mfma_obs_stats_f64(srx_context* h, const void* X, const void* gamma, const int64_t* off,
