@@ -20,6 +20,7 @@
 #include "srx_internal.h"
 
 #include <type_traits>
+#include <utility>
 
 #include <math.h>
 
@@ -111,17 +112,61 @@ __global__ void emission_kernel(const T* __restrict__ X, const int64_t* __restri
     }
 }
 
-template <typename T, int SP>
-__device__ __forceinline__ T sub_sum(T v) {
+// Lane exchange inside a sub-wave of SP <= 16 lanes, which is (part of) one DPP row: a
+// v_mov_b32_dpp per 32-bit half has the latency of a vector instruction, where __shfl /
+// __shfl_xor go through the LDS crossbar (ds_bpermute) and cost ten times that on the
+// serial path of a chain.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    const unsigned u = __float_as_uint(v);
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(u, u, CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+    lo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// Partner of each reduction stage: lane 15 - i (row_mirror), 7 - i inside a half row
+// (row_half_mirror), i ^ 2 and i ^ 1 (quad_perm).  After every stage the values are
+// symmetric under the next stage's pairing, so all lanes end with the same bits.
+template <typename T, int SP, typename F>
+__device__ __forceinline__ T sub_reduce(T v, F&& op) {
+    if constexpr (SP <= 16) {
+        if constexpr (SP >= 16) v = op(v, dpp_mov<0x140>(v));
+        if constexpr (SP >= 8) v = op(v, dpp_mov<0x141>(v));
+        if constexpr (SP >= 4) v = op(v, dpp_mov<0x4E>(v));
+        if constexpr (SP >= 2) v = op(v, dpp_mov<0xB1>(v));
+    } else {
 #pragma unroll
-    for (int o = SP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, SP);
+        for (int o = SP / 2; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o, SP));
+    }
     return v;
 }
 template <typename T, int SP>
+__device__ __forceinline__ T sub_sum(T v) {
+    return sub_reduce<T, SP>(v, [](T a, T b) { return a + b; });
+}
+template <typename T, int SP>
 __device__ __forceinline__ T sub_max(T v) {
-#pragma unroll
-    for (int o = SP / 2; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, SP));
-    return v;
+    return sub_reduce<T, SP>(v, [](T a, T b) { return (T)fmax(a, b); });
+}
+// Value of lane I of the sub-wave in every lane: row_newbcast for a whole row.
+template <typename T, int SP, int I>
+__device__ __forceinline__ T sub_bcast(T v) {
+    if constexpr (SP == 16) return dpp_mov<0x150 + I>(v);
+    else return __shfl(v, I, SP);
+}
+// f(integral_constant<int, i>) for i = 0 .. SP-1, in order.
+template <typename F, int... I>
+__device__ __forceinline__ void for_lanes_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int SP, typename F>
+__device__ __forceinline__ void for_lanes(F&& f) {
+    for_lanes_impl(f, std::make_integer_sequence<int, SP>{});
 }
 
 template <typename T> __device__ __forceinline__ T neg_inf();
@@ -159,8 +204,10 @@ __global__ void score_chain_kernel(const T* __restrict__ loglik, const int64_t* 
                 a = pij * b;
             } else {
                 a = 0;
-#pragma unroll
-                for (int i = 0; i < SP; ++i) a += __shfl(alpha, i, SP) * acol[i];
+                for_lanes<SP>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    a += sub_bcast<T, SP, i>(alpha) * acol[i];
+                });
                 a *= b;
             }
             const T c = sub_sum<T, SP>(a);
@@ -229,8 +276,10 @@ __global__ void fb_chain_kernel(const T* __restrict__ loglik, const int64_t* __r
                 a = pij * b;
             } else {
                 a = 0;
-#pragma unroll
-                for (int i = 0; i < SP; ++i) a += __shfl(alpha, i, SP) * acol[i];
+                for_lanes<SP>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    a += sub_bcast<T, SP, i>(alpha) * acol[i];
+                });
                 a *= b;
             }
             const T c = sub_sum<T, SP>(a);
@@ -254,12 +303,12 @@ __global__ void fb_chain_kernel(const T* __restrict__ loglik, const int64_t* __r
                 beta = ci;
             } else {
                 T s = 0;
-#pragma unroll
-                for (int i = 0; i < SP; ++i) {
-                    const T w = arow[i] * __shfl(bb, i, SP);
+                for_lanes<SP>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    const T w = arow[i] * sub_bcast<T, SP, i>(bb);
                     s += w;
                     xi[i] += al * w;
-                }
+                });
                 beta = s * ci;
             }
             T g = al * beta;
@@ -414,14 +463,14 @@ __global__ void viterbi_chain_kernel(const T* __restrict__ loglik,
         for (int t = 1; t < T_len; ++t) {
             T best = neg_inf<T>();
             int arg = 0;
-#pragma unroll
-            for (int i = 0; i < SP; ++i) {
-                const T cand = __shfl(v, i, SP) + lacol[i];
+            for_lanes<SP>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const T cand = sub_bcast<T, SP, i>(v) + lacol[i];
                 if (cand > best) {   // strict: the lowest index wins ties (np.argmax)
                     best = cand;
                     arg = i;
                 }
-            }
+            });
             if (j < S) {
                 v = best + ll[(int64_t)t * S];
                 b[(int64_t)t * S] = (uint8_t)arg;
