@@ -153,6 +153,24 @@ template <typename T, int SP>
 __device__ __forceinline__ T sub_max(T v) {
     return sub_reduce<T, SP>(v, [](T a, T b) { return (T)fmax(a, b); });
 }
+// log P(x) = sum_t (mx_t + log c_t) without a logarithm per step (a software f64 log is
+// ~50 instructions on the chain's serial path): the product of the c_t is carried as a
+// mantissa in [0.5, 1) and a binary exponent, renormalised every step with the two frexp
+// instructions; one logarithm at the end.  c == 0 gives -inf, as log(0) did.
+struct LogProduct {
+    double shift = 0.0, mant = 1.0;
+    long long expo = 0;
+    __device__ __forceinline__ void step(double mx, double c) {
+        shift += mx;
+        int e;
+        mant = frexp(mant * c, &e);
+        expo += e;
+    }
+    __device__ __forceinline__ double value() const {
+        return shift + ((double)expo * 0.6931471805599453 + log(mant));
+    }
+};
+
 // Value of lane I of the sub-wave in every lane: row_newbcast for a whole row.
 template <typename T, int SP, int I>
 __device__ __forceinline__ T sub_bcast(T v) {
@@ -194,7 +212,7 @@ __global__ void score_chain_kernel(const T* __restrict__ loglik, const int64_t* 
         const T pij = j < S ? tb.pi[m * S + j] : (T)0;
         const T* ll = loglik + f0 * NC + m * S + j;
         T alpha = 0;
-        double lp = 0.0;
+        LogProduct lpp;
         for (int t = 0; t < T_len; ++t) {
             const T l = j < S ? ll[(int64_t)t * NC] : neg_inf<T>();
             const T mx = sub_max<T, SP>(l);
@@ -211,10 +229,10 @@ __global__ void score_chain_kernel(const T* __restrict__ loglik, const int64_t* 
                 a *= b;
             }
             const T c = sub_sum<T, SP>(a);
-            lp += (double)mx + log((double)c);
+            lpp.step((double)mx, (double)c);
             alpha = a / c;
         }
-        if (j == 0) out[chain] = lp;
+        if (j == 0) out[chain] = lpp.value();
     }
 }
 
@@ -266,7 +284,7 @@ __global__ void fb_chain_kernel(const T* __restrict__ loglik, const int64_t* __r
         T* sc = scale + f0;
         // ---- forward
         T alpha = 0;
-        double lp = 0.0;
+        LogProduct lpp;
         for (int t = 0; t < T_len; ++t) {
             const T l = j < S ? ll[(int64_t)t * S] : neg_inf<T>();
             const T mx = sub_max<T, SP>(l);
@@ -283,12 +301,13 @@ __global__ void fb_chain_kernel(const T* __restrict__ loglik, const int64_t* __r
                 a *= b;
             }
             const T c = sub_sum<T, SP>(a);
-            lp += (double)mx + log((double)c);
+            lpp.step((double)mx, (double)c);
             const T ci = (T)1 / c;
             alpha = a * ci;
             if (j < S) la[(int64_t)t * S] = alpha;
             if (j == 0) sc[t] = ci;
         }
+        const double lp = lpp.value();
         // ---- backward, posteriors, xi
         T xi[SP];
 #pragma unroll
