@@ -243,7 +243,7 @@ __global__ void score_chain_kernel(const T* __restrict__ loglik, const int64_t* 
 // With partial == NULL only the posteriors and utt_lp[u] (per-utterance
 // log-probability, may itself be NULL otherwise) are produced.
 template <typename T, int SP>
-__global__ void fb_chain_kernel(const T* __restrict__ loglik, const int64_t* __restrict__ off,
+__global__ void fb_chain_kernel(T* __restrict__ loglik, const int64_t* __restrict__ off,
                                 int64_t U, const int32_t* __restrict__ utt_model,
                                 const int64_t* __restrict__ utt_order, int M, int S,
                                 Tables<T> tb, T* __restrict__ lat, T* __restrict__ scale,
@@ -279,16 +279,18 @@ __global__ void fb_chain_kernel(const T* __restrict__ loglik, const int64_t* __r
             arow[i] = (i < S && j < S) ? tb.A[((size_t)m * S + j) * S + i] : (T)0;
         }
         const T pij = j < S ? tb.pi[m * S + j] : (T)0;
-        const T* ll = loglik + f0 * S + j;
+        T* ll = loglik + f0 * S + j;
         T* la = lat + f0 * S + j;
         T* sc = scale + f0;
-        // ---- forward
+        // ---- forward (the shifted densities b~ replace the log-densities in the
+        // workspace: the backward pass reads them instead of exponentiating again)
         T alpha = 0;
         LogProduct lpp;
         for (int t = 0; t < T_len; ++t) {
             const T l = j < S ? ll[(int64_t)t * S] : neg_inf<T>();
             const T mx = sub_max<T, SP>(l);
             const T b = j < S ? exp(l - mx) : (T)0;
+            if (j < S) ll[(int64_t)t * S] = b;
             T a;
             if (t == 0) {
                 a = pij * b;
@@ -335,9 +337,7 @@ __global__ void fb_chain_kernel(const T* __restrict__ loglik, const int64_t* __r
             if (gs == (T)0) gs = (T)1;   // utils.normalize: zero rows divide by 1
             g = g / gs;
             if (j < S) la[(int64_t)t * S] = g;
-            const T l = j < S ? ll[(int64_t)t * S] : neg_inf<T>();
-            const T mx = sub_max<T, SP>(l);
-            const T b = j < S ? exp(l - mx) : (T)0;
+            const T b = j < S ? ll[(int64_t)t * S] : (T)0;
             bb = b * beta;
             gamma0 = g;
         }
@@ -1031,7 +1031,7 @@ int posteriors_t(srx_context* h, const void* X, const int64_t* off, int64_t U, i
     const int sp = sub_width(S);
     SP_DISPATCH(sp, hipLaunchKernelGGL((fb_chain_kernel<T, SP>),
                                        dim3(grid_for(h, U, kBlock / SP)), dim3(kBlock), 0, st,
-                                       (const T*)ll, off, U, utt_model, (const int64_t*)nullptr, M,
+                                       (T*)ll, off, U, utt_model, (const int64_t*)nullptr, M,
                                        S, tb, (T*)gamma, sc, (double*)nullptr, lp, 1));
     SRX_HIP(hipGetLastError());
     return SRX_OK;
@@ -1079,7 +1079,7 @@ int estep_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_
         hipLaunchKernelGGL(emission_kernel<T>, dim3(grid_for(h, U, 1)), dim3(kBlock), 0, st,
                            (const T*)X, off, U, utt_model, 0, M, S, D, tb, ll);
     SP_DISPATCH(sp, hipLaunchKernelGGL((fb_chain_kernel<T, SP>), dim3(g_fb), dim3(kBlock), lds, st,
-                                       (const T*)ll, off, U, utt_model, utt_order, M, S, tb, lat,
+                                       (T*)ll, off, U, utt_model, utt_order, M, S, tb, lat,
                                        sc, part, (double*)nullptr, acc_in_lds));
     const int slots = (S * D + kBlock - 1) / kBlock;
     SRX_REQUIRE(slots <= 16, "estep: n_states*n_features = %d exceeds %d", S * D, 16 * kBlock);
