@@ -187,6 +187,23 @@ int srx_forward_score_generic(srx_handle_t h, const void* X, int dtype,
                               const int64_t* utt_offsets, int64_t n_utts, int64_t n_frames,
                               const srx_models_t* models, double* out_scores, void* stream);
 
+/* Allocation-free variant of srx_forward_score (same arguments, same results, SRX_F32
+ * only).  It has no counterpart in the reference: it is for callers that cannot allocate
+ * device memory while they run -- code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  The prepared model tables, which srx_forward_score
+ * keeps in the context's hipMalloc'ed workspace, live in a fixed device array of
+ * srx_static_scratch_bytes() (256 KiB) that every GPU the library runs on holds until
+ * the process ends; no hipMalloc / hipFree is made.  Limits: n_states <= 16,
+ * n_features <= 48, default (split-bf16) arithmetic, and a bank whose tables fit the
+ * array (about 40 sixteen-row tiles: 80 models of 8 states, 40 of 16 states at 39
+ * features); anything else returns SRX_EUNSUPPORTED or, for a bank that is too large,
+ * SRX_EINVAL with the sizes in srx_last_error().  All contexts of one GPU share the
+ * array: two calls that overlap on one GPU (two streams, two threads) race on it. */
+int srx_forward_score_static(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
+                             int64_t n_utts, int64_t n_frames, const srx_models_t* models,
+                             double* out_scores, void* stream);
+int64_t srx_static_scratch_bytes(void);
+
 /* ---- decoding: utils.viterbi, utils.py:243-266 (decode, hmm.py:357-373, is
  * broken in the reference).  utt_model[u] (int32, may be NULL = model 0)
  * selects the model; out_path[f] int32 state per frame, out_logprob[u]. */

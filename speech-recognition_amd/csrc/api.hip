@@ -7,8 +7,36 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+
 namespace {
 thread_local char g_err[512] = "";
+
+// Table memory of srx_forward_score_static: a fixed device array instead of the
+// context's hipMalloc'ed workspace, for callers that must not allocate.  Every GPU
+// holds its own copy at its own address; the address is looked up once per device
+// in srx_create (the array's name is only a host-side handle for that lookup and is
+// never passed to a kernel or a memory routine).
+constexpr size_t kStaticScratchBytes = 256 * 1024;
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) __attribute__((used)) unsigned char scratch[kStaticScratchBytes];
+void* g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mutex;
+
+// With `device` current: the address of this device's copy of `scratch`.
+int static_scratch_for(int device, void** out) {
+    SRX_REQUIRE(device >= 0 && device < kMaxDevices, "device %d: at most %d devices are supported",
+                device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        SRX_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        SRX_REQUIRE(p != nullptr, "hipGetSymbolAddress returned a NULL address for device %d", device);
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return SRX_OK;
+}
 }
 
 void srx_set_error(const char* fmt, ...) {
@@ -87,10 +115,14 @@ int srx_create(int device, srx_handle_t* out) {
                       prop.gcnArchName);
         return SRX_EUNSUPPORTED;
     }
+    void* sp = nullptr;
+    int rc = static_scratch_for(device, &sp);
+    if (rc) return rc;
     srx_context* h = new srx_context();
     memset(h, 0, sizeof(*h));
     h->device = device;
     h->n_cu = prop.multiProcessorCount;
+    h->static_scratch = sp;
     *out = h;
     return SRX_OK;
 }
@@ -209,6 +241,31 @@ int srx_forward_score(srx_handle_t h, const void* X, int dtype, const int64_t* u
     }
     return srx_generic_score(h, X, dtype, utt_offsets, n_utts, n_frames, models, out_scores,
                              (hipStream_t)stream);
+}
+
+int64_t srx_static_scratch_bytes(void) { return (int64_t)kStaticScratchBytes; }
+
+int srx_forward_score_static(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
+                             int64_t n_utts, int64_t n_frames, const srx_models_t* models,
+                             double* out_scores, void* stream) {
+    int rc = check_common(h, X, dtype, n_utts, n_frames, utt_offsets, "srx_forward_score_static");
+    if (rc) return rc;
+    if ((rc = check_models(models, "srx_forward_score_static"))) return rc;
+    if (dtype != SRX_F32 || models->n_states > 16 || models->n_features > 48 || h->exact_f32) {
+        srx_set_error("srx_forward_score_static: only SRX_F32 with n_states <= 16, n_features <= 48 and "
+                      "the default (split-bf16) arithmetic has an allocation-free kernel");
+        return SRX_EUNSUPPORTED;
+    }
+    if (n_utts == 0) return SRX_OK;
+    SRX_REQUIRE(out_scores != nullptr, "srx_forward_score_static: NULL out_scores");
+    SRX_REQUIRE(n_frames > 0, "srx_forward_score_static: no frames");
+    SRX_HIP(hipSetDevice(h->device));
+    rc = srx_mfma_score_tables(h, X, utt_offsets, n_utts, n_frames, models, out_scores,
+                               h->static_scratch, kStaticScratchBytes, (hipStream_t)stream);
+    if (rc == SRX_EUNSUPPORTED)
+        srx_set_error("srx_forward_score_static: no allocation-free kernel for n_models=%d n_states=%d "
+                      "n_features=%d", models->n_models, models->n_states, models->n_features);
+    return rc;
 }
 
 int srx_forward_score_generic(srx_handle_t h, const void* X, int dtype,

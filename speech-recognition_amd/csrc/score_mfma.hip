@@ -627,8 +627,15 @@ int srx_mfma_emission_utt_f32(srx_context* h, const void* X, const int64_t* off,
 
 int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
                    const srx_models_t* md, double* out, hipStream_t st) {
+    return srx_mfma_score_tables(h, X, off, U, n_frames, md, out, nullptr, 0, st);
+}
+
+int srx_mfma_score_tables(srx_context* h, const void* X, const int64_t* off, int64_t U,
+                          int64_t n_frames, const srx_models_t* md, double* out, void* tables,
+                          size_t tables_bytes, hipStream_t st) {
     const int M = md->n_models, S = md->n_states, D = md->n_features;
     if (S > 16 || D > 48 || n_frames <= 0) return SRX_EUNSUPPORTED;
+    if (tables && h->exact_f32) return SRX_EUNSUPPORTED;
     if (h->exact_f32 && (D > 40 || S > 8)) return SRX_EUNSUPPORTED;
     const int SP = S <= 4 ? 4 : (S <= 8 ? 8 : 16);
     const int NT = (M * SP + 15) / 16;
@@ -646,9 +653,19 @@ int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
         const int NTP = chunks * NTC;
         const size_t n_wp = (size_t)NTP * 16 * (RQ + H) * 2 * 4 * 4, n_c = (size_t)NTP * 16;
         unsigned* base;
-        int rc = srx_ws_ensure(h, WS_PARAMS,
-                               4 * (n_wp + n_c + (size_t)M * S * S + (size_t)M * S), (void**)&base);
-        if (rc) return rc;
+        const size_t need = 4 * (n_wp + n_c + (size_t)M * S * S + (size_t)M * S);
+        if (tables) {
+            if (need > tables_bytes) {
+                srx_set_error("model bank too large for the caller's table memory: its tables need %zu "
+                              "bytes, %zu are there (n_models=%d n_states=%d n_features=%d)",
+                              need, tables_bytes, M, S, D);
+                return SRX_EINVAL;
+            }
+            base = (unsigned*)tables;
+        } else {
+            int rc = srx_ws_ensure(h, WS_PARAMS, need, (void**)&base);
+            if (rc) return rc;
+        }
         float* cst = (float*)(base + n_wp);
         float* A = cst + n_c;
         float* pi = A + (size_t)M * S * S;
@@ -660,7 +677,7 @@ int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
         return SP == 8 ? srx_split_score_sp8(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st)
                        : srx_split_score_sp4(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st);
     }
-    if (NT > 3) return SRX_EUNSUPPORTED;
+    if (NT > 3 || tables) return SRX_EUNSUPPORTED;
     const int KQ = 4 * R;
     const size_t n_w = (size_t)NT * 16 * KQ * 4, n_c = (size_t)NT * 16;
     float* base;

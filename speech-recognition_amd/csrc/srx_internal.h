@@ -26,6 +26,7 @@ struct srx_context {
     int exact_f32;   // SRX_OPT_EXACT_F32: keep the float32 paths on exact-f32 matrix instructions
     void* ws[WS_NUM];
     size_t ws_bytes[WS_NUM];
+    void* static_scratch;   // this device's copy of the fixed table array (api.hip)
 };
 
 struct srx_mfcc_plan {
@@ -125,6 +126,12 @@ int srx_mfma_emission_utt_f32(srx_context* h, const void* X, const int64_t* off,
 int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
                    int64_t n_frames, const srx_models_t* models, double* out,
                    hipStream_t st);
+// The same with the prepared tables in memory the caller brings (`tables`, at least
+// `tables_bytes` long, 16-byte aligned) instead of the context's workspace: nothing is
+// allocated.  Only the split-bf16 kernels; SRX_EINVAL when the tables do not fit.
+int srx_mfma_score_tables(srx_context* h, const void* X, const int64_t* off, int64_t U,
+                          int64_t n_frames, const srx_models_t* models, double* out, void* tables,
+                          size_t tables_bytes, hipStream_t st);
 
 // Implemented in score_f64.hip: float64 scoring on the f64 matrix instruction (<= 8 states,
 // <= 48 features), else SRX_EUNSUPPORTED.

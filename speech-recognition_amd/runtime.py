@@ -213,6 +213,17 @@ class HMMBank:
                  C.byref(self._struct), ptr(out), self.ctx.stream_ptr()), "srx_forward_score")
         return out
 
+    def score_static(self, data, out):
+        """``score`` through srx_forward_score_static: float32 only, no device memory is
+        allocated (``out`` must be the caller's (U, M) float64 tensor)."""
+        self._check(data)
+        if out is None or tuple(out.shape) != (data.U, self.M) or out.dtype != torch.float64:
+            raise ValueError("out must be a (U, M) float64 device tensor")
+        check(lib.srx_forward_score_static(self.ctx.handle, ptr(data.X), data.code, ptr(data.offsets),
+                                           data.U, data.n_frames, C.byref(self._struct), ptr(out),
+                                           self.ctx.stream_ptr()), "srx_forward_score_static")
+        return out
+
     def viterbi(self, data, utt_model=None):
         self._check(data)
         path = torch.empty((data.n_frames,), dtype=torch.int32, device=self.ctx.device)
