@@ -1,20 +1,31 @@
 #!/usr/bin/env python
 """Headline benchmark: batched HMM scoring, 65,536 synthetic utterances x 200
 frames x 39-dim features against 6 word models of 8 states, on N GPUs of one node
-(utterances sharded, no collective).
+(utterances sharded, no collective), and Baum-Welch iterations/s on the config's
+1,048,576 utterances (6 models x 16 states, one all-reduce of the statistics per
+iteration).
 
-    python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus N --steps 10 --warmup 2
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+With --gpus N > 1 and no RANK in the environment this process only launches N
+children (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), before any
+GPU call of its own, waits for them and exits with their status; under
+torch.distributed.run the ranks are already there and nothing is launched.
 
 A step is one pass of srx_forward_score over the rank's batch, inputs resident
 in HBM.  Rank 0 prints ONE JSON line.  Beside the headline it carries
   roofline      algorithmic HBM bytes (156 B/frame in + 48 B/utterance out)
                 / event-timed duration of the scoring launch, against 8 TB/s
-  cpu_baseline  the loop-faithful fp64 CPU oracle on a bounded sample
-  extra         front-end frames/s (16 kHz, 512-pt FFT, 40 mel, 39-dim), Baum-Welch
-                iterations/s (6 models x 16 states), emission, Viterbi, posteriors,
-                end-pointing and the large-model lines, each with its own size,
-                measured outside the timed region of the headline.
+  cpu_baseline  the loop-faithful fp64 CPU oracle on a bounded sample (N = 1)
+  baum_welch_iter_per_s, allreduce_ms_per_iter, rccl_ranks
+                the training metric (fixed total work: strong scaling), the time of
+                the statistics all-reduce alone, and the rank count an actual
+                all-reduce over the process group returned
+  extra         (N = 1) front-end frames/s (16 kHz, 512-pt FFT, 40 mel, 39-dim),
+                emission, Viterbi, posteriors, end-pointing and the large-model
+                lines, each with its own size, measured outside the timed region
+                of the headline.
 """
 import argparse
 import json
@@ -88,6 +99,38 @@ def cpu_baseline(sample_utts, seed=1234):
     return res
 
 
+def launch_ranks(n, argv, dry_run=False):
+    """Start one child per GPU and wait.  The parent makes no GPU call (a process
+    that has initialised the GPU must not be replaced or forked).  Returns the exit
+    status: 0 only if every rank succeeded."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    pending = dict(enumerate(procs))
+    while pending:
+        for r, p in list(pending.items()):
+            try:
+                code = p.wait(timeout=0.2)
+            except subprocess.TimeoutExpired:
+                continue
+            del pending[r]
+            if code != 0:
+                rc = rc or code or 1
+                print(f"bench.py: rank {r} exited with status {code}", file=sys.stderr, flush=True)
+                for q in pending.values():       # a failed rank leaves the others in a collective
+                    q.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,7 +146,32 @@ def main():
     ap.add_argument("--train-utts", type=int, default=0,
                     help="utterances per GPU for the Baum-Welch extra (default: the config's "
                          "1,048,576 utterances in total, split over the GPUs)")
+    ap.add_argument("--no-train", action="store_true", help="skip the Baum-Welch measurement")
+    ap.add_argument("--all-extra", action="store_true",
+                    help="run the secondary extra lines on more than one GPU too")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses GPU 0 (needs --backend gloo, "
+                         "RCCL refuses two ranks on one device)")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="launcher check: every rank prints its rank environment and exits "
+                         "without touching a GPU")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.dry_run_launch:
+        print(json.dumps({k: os.environ.get(k) for k in
+                          ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}),
+              flush=True)
+        return
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}; "
+              "the launched rank count is what runs", file=sys.stderr)
+
+    if os.environ.get("SRX_BENCH_WATCHDOG"):          # debugging aid: where does a rank hang?
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["SRX_BENCH_WATCHDOG"]), exit=True)
 
     import torch
     import torch.distributed as dist
@@ -111,10 +179,13 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
     dev = torch.device("cuda", local)
     ctx = sra.Context.default(local)
 
@@ -170,7 +241,10 @@ def main():
         "metric": "hmm_scored_frames_per_sec_6_models", "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": "f32 (emission contraction as 3 split-bf16 partial products on the bf16 matrix "
+                 "instruction, f32 accumulate; recursion f32; log-probability summed in f64)",
+        "data": "synthetic",
         "config": {"workload": "batched scoring: 65,536 utterances x 200 frames x 39-dim vs 6 HMMs "
                                "x 8 states (diag Gaussians)",
                    "utterances_per_gpu": U, "frames_per_utterance": T_FRAMES,
@@ -182,9 +256,18 @@ def main():
         "checksum": checksum,
     }
 
+    # what the arithmetic named in "dtype" costs: the same scores in float64 (the validation
+    # dtype, every product on the f64 matrix instruction) on the first utterances of the batch
+    n_sub = min(U, 8192)
+    d64 = sra.Ragged(ctx, X[:n_sub * T_FRAMES].double(), offsets=offsets[:n_sub + 1], dtype="float64")
+    sc64 = bank.score(d64)
+    out["max_rel_err_vs_f64"] = float(((sc64 - scores[:n_sub]).abs() / sc64.abs()).max().item())
+    out["max_rel_err_vs_f64_utterances"] = n_sub
+    del d64, sc64
+
     # ------------------------------------------------------------------ extras
-    if not args.no_extra:
-        extra = {}
+    extra = {}
+    if not args.no_extra and (world == 1 or args.all_extra):
         # stand-alone emission log-likelihoods and Viterbi decoding on the scoring batch
         ll = bank.emission_loglik(data)
         barrier()
@@ -296,35 +379,8 @@ def main():
                              "config": "8192 recordings x 3 s at 16 kHz, float32 (4 B in per sample)"}
         del audio, feats, ep
         torch.cuda.empty_cache()
-        # Baum-Welch: 6 models x 16 states, utterance u trains model u mod 6
-        Ut = args.train_utts if args.train_utts > 0 else (1 << 20) // world
-        g3 = torch.Generator(device=dev)
-        g3.manual_seed(4321 + rank)
-        Xt = torch.empty((Ut * T_FRAMES, N_FEAT), device=dev, dtype=torch.float32)
-        for i0 in range(0, Ut * T_FRAMES, 1 << 24):          # 31 GB at one GPU: fill in pieces
-            Xt[i0:i0 + (1 << 24)].normal_(generator=g3)
-        offt = torch.arange(0, (Ut + 1) * T_FRAMES, T_FRAMES, device=dev, dtype=torch.int64)
-        dt_ = sra.Ragged(ctx, Xt, offsets=offt, dtype="float32")
-        sp2, A2, mu2, cv2 = synth_models(np.random.default_rng(8), N_MODELS, 16, N_FEAT)
-        bank2 = sra.HMMBank(ctx, sp2, A2, mu2, cv2)
-        tr = sra.parallel.BaumWelchTrainer(bank2, dt_, np.arange(Ut) % N_MODELS)
-        tr.step()
-        barrier()
-        t0 = time.perf_counter()
-        iters = 3
-        for _ in range(iters):
-            lp = tr.step()
-        barrier()
-        dtt = (time.perf_counter() - t0) / iters
-        extra["baum_welch"] = {"iter_per_s": 1.0 / dtt, "ms_per_iter": dtt * 1e3,
-                               "utterances_total": Ut * world, "frames_per_s": Ut * world * T_FRAMES / dtt,
-                               "scaling": "strong (fixed total)" if args.train_utts <= 0 else "weak",
-                               "config": "6 models x 16 states x 39 dims, full M-step, stats all-reduce",
-                               "logprob_model0": float(lp[0].item())}
         if not args.no_large:
             # large model: 1024 states x 16-component diagonal GMMs x 39 dims, 4096 x 200 frames
-            del Xt, dt_, tr
-            torch.cuda.empty_cache()
             Sl, Ml, Ul = 1024, 16, args.large_utts
             rl = np.random.default_rng(5)
             em = sra.GmmEmission(ctx, rl.dirichlet(np.ones(Ml), size=Sl),
@@ -362,6 +418,68 @@ def main():
                 "tera_maxplus_per_s": Ul * T_FRAMES * float(Sl) * Sl / dlv / 1e12,
                 "config": "dense 1024 x 1024 log A, (max,+) S^2 per frame on the vector ALUs, "
                           "backtrace by recomputation"}
+
+    # ---------------------------------------------------------------- training
+    # Baum-Welch on the config's 1,048,576 utterances in total (fixed total work: strong
+    # scaling), 6 models x 16 states, utterance u trains model u mod 6; one EM iteration =
+    # E-step over the rank's shard + ONE all-reduce of all models' statistics + M-step
+    if not args.no_train:
+        for name in ("X", "data", "scores"):
+            locals().pop(name, None)
+        X = data = scores = None
+        torch.cuda.empty_cache()
+        Ut = args.train_utts if args.train_utts > 0 else (1 << 20) // world
+        g3 = torch.Generator(device=dev)
+        g3.manual_seed(4321 + rank)
+        Xt = torch.empty((Ut * T_FRAMES, N_FEAT), device=dev, dtype=torch.float32)
+        for i0 in range(0, Ut * T_FRAMES, 1 << 24):          # 31 GB at one GPU: fill in pieces
+            Xt[i0:i0 + (1 << 24)].normal_(generator=g3)
+        offt = torch.arange(0, (Ut + 1) * T_FRAMES, T_FRAMES, device=dev, dtype=torch.int64)
+        dt_ = sra.Ragged(ctx, Xt, offsets=offt, dtype="float32")
+        sp2, A2, mu2, cv2 = synth_models(np.random.default_rng(8), N_MODELS, 16, N_FEAT)
+        bank2 = sra.HMMBank(ctx, sp2, A2, mu2, cv2)
+        tr = sra.parallel.BaumWelchTrainer(bank2, dt_, np.arange(Ut) % N_MODELS)
+        tr.step()
+        barrier()
+        t0 = time.perf_counter()
+        iters = 5
+        for _ in range(iters):
+            lp = tr.step()
+        barrier()
+        dtt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dtt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtt = float(t.item())
+        dtt /= iters
+        # the exchange step alone: the all-reduce of the packed float64 records, back to back
+        ar_ms, ranks_seen = 0.0, 1
+        if world > 1:
+            one = torch.ones((1,), device=dev, dtype=torch.float64)
+            dist.all_reduce(one, op=dist.ReduceOp.SUM)
+            ranks_seen = int(round(float(one.item())))
+            buf = tr.stats.clone()
+            for _ in range(5):
+                sra.parallel.allreduce_stats(buf)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                sra.parallel.allreduce_stats(buf)
+            torch.cuda.synchronize()
+            ar_ms = (time.perf_counter() - t0) / 50 * 1e3
+        out["baum_welch_iter_per_s"] = 1.0 / dtt
+        out["allreduce_ms_per_iter"] = ar_ms
+        out["rccl_ranks"] = ranks_seen
+        out["collective_backend"] = dist.get_backend() if world > 1 else None
+        extra["baum_welch"] = {"iter_per_s": 1.0 / dtt, "ms_per_iter": dtt * 1e3,
+                               "utterances_total": Ut * world, "frames_per_s": Ut * world * T_FRAMES / dtt,
+                               "scaling": "strong (fixed total)" if args.train_utts <= 0 else "weak",
+                               "config": "6 models x 16 states x 39 dims, full M-step, one all-reduce of "
+                                         f"{tr.stats.numel()} float64 per iteration",
+                               "allreduce_ms": ar_ms, "rccl_ranks": ranks_seen,
+                               "logprob_model0": float(lp[0].item())}
+        del Xt, dt_, tr
+    if extra:
         out["extra"] = extra
 
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -42,7 +42,14 @@ def allreduce_stats(stats):
     all models (S=16, D=39, 6 models: 9228 doubles = 74 KB, latency-bound)."""
     _, n = world()
     if n > 1:
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        if stats.is_cuda and dist.get_backend() == "gloo":
+            # gloo's own handling of device tensors stalls on buffers of this size when two
+            # ranks share a GPU (the rehearsal set-up of a one-GPU box): stage through the host
+            host = stats.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            stats.copy_(host)
+        else:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     return stats
 
 

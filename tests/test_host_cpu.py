@@ -149,3 +149,141 @@ def test_two_rank_stats_allreduce_gloo():
         p.join(180)
         assert p.exitcode == 0
     assert ret.get(0) and ret.get(1)
+
+
+def test_bench_launcher_starts_one_rank_per_gpu():
+    """`bench.py --gpus 2` without RANK in the environment launches two ranks before any
+    GPU call (checked with --dry-run-launch: the children print their rank environment
+    and never import torch.cuda)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                        "--dry-run-launch"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    recs = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")),
+                  key=lambda d: d["RANK"])
+    assert [d["RANK"] for d in recs] == ["0", "1"]
+    assert [d["LOCAL_RANK"] for d in recs] == ["0", "1"]
+    assert all(d["WORLD_SIZE"] == "2" and d["MASTER_ADDR"] == "127.0.0.1" for d in recs)
+    assert recs[0]["MASTER_PORT"] == recs[1]["MASTER_PORT"]
+    # under torch.distributed.run the ranks exist already: nothing more is launched
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                        "--dry-run-launch"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1
+
+
+class _OracleBank:
+    """Stand-in for HMMBank on a machine without a GPU: the same methods the trainer calls,
+    with the CPU oracle in place of the kernels and CPU tensors in place of device memory."""
+
+    class _Ctx:
+        def __init__(self):
+            import torch
+            self.device = torch.device("cpu")
+
+        def tensor(self, a, dtype=None):
+            import torch
+            return torch.from_numpy(np.ascontiguousarray(a))
+
+    def __init__(self, params, X, lengths):
+        from oracle import hmm_oracle as ho
+        self.ho, self.ctx = ho, self._Ctx()
+        self.params = list(params)
+        self.M = len(params)
+        self.S, self.D = params[0].means.shape
+        self.stats_size = 2 + self.S + self.S * self.S + self.S + 2 * self.S * self.D
+        self.X, self.lengths = X, np.asarray(lengths)
+
+    def estep(self, data, utt_model, utt_order, out=None):
+        ho = self.ho
+        off = np.concatenate([[0], np.cumsum(self.lengths)])
+        um = utt_model.numpy()
+        for m in range(self.M):
+            idx = [u for u in range(len(self.lengths)) if um[u] == m]
+            rec = np.zeros(self.stats_size)
+            if idx:
+                Xm = np.vstack([self.X[off[u]:off[u + 1]] for u in idx])
+                st, lps = ho.estep(self.params[m], Xm, self.lengths[idx], loops=False)
+                rec = np.concatenate([[st["nobs"], lps.sum()], st["start"], st["trans"].ravel(),
+                                      st["post"], st["obs"].ravel(), st["obs**2"].ravel()])
+            out[m] = __import__("torch").from_numpy(rec)
+        return out
+
+    def unpack(self, rec):
+        S, D = self.S, self.D
+        o = 2
+        d = {"nobs": rec[0]}
+        d["start"] = rec[o:o + S]; o += S
+        d["trans"] = rec[o:o + S * S].reshape(S, S); o += S * S
+        d["post"] = rec[o:o + S]; o += S
+        d["obs"] = rec[o:o + S * D].reshape(S, D); o += S * D
+        d["obs**2"] = rec[o:o + S * D].reshape(S, D)
+        return d
+
+    def mstep(self, stats, priors, mode):
+        f = self.ho.mstep_full if mode == "full" else self.ho.mstep_transitions
+        self.params = [f(p, self.unpack(stats[m].numpy())) for m, p in enumerate(self.params)]
+
+
+class _Shard:
+    def __init__(self, X, lengths):
+        import torch
+        self.X, self.U = torch.from_numpy(X), len(lengths)
+
+
+def _trainer_rank_main(rank, world, port, ret):
+    """Three EM iterations of BaumWelchTrainer.step on this rank's shard: E-step, the
+    package's all-reduce, replicated M-step.  Every rank must end with the parameters of a
+    single-process run over all utterances, and report the global log-probabilities."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from oracle import hmm_oracle as ho
+    from speech_recognition_amd import parallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(11)
+    S, D, M = 3, 5, 2
+    prms = [ho.random_params(rng, S, D) for _ in range(M)]
+    lengths = rng.integers(1, 30, size=31)
+    um = (np.arange(len(lengths)) % M).astype(np.int32)
+    X = rng.standard_normal((int(lengths.sum()), D))
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    lo, hi = parallel.shard_utterances(lengths, rank, world)
+    Xs, Ls = X[off[lo]:off[hi]], lengths[lo:hi]
+    bank = _OracleBank(prms, Xs, Ls)
+    tr = parallel.BaumWelchTrainer(bank, _Shard(Xs, Ls), um[lo:hi], mstep="full")
+    single = _OracleBank(prms, X, lengths)
+    ok = True
+    for it in range(3):
+        lp = tr.step().numpy()
+        import torch
+        st = torch.zeros((M, single.stats_size), dtype=torch.float64)
+        single.estep(None, torch.from_numpy(um), None, out=st)
+        lp1 = st[:, 1].numpy().copy()
+        single.mstep(st, None, "full")
+        ok = ok and np.allclose(lp, lp1, rtol=1e-10)
+        for a, b in zip(bank.params, single.params):
+            ok = ok and np.allclose(a.A, b.A, rtol=1e-9, atol=1e-12) \
+                and np.allclose(a.means, b.means, rtol=1e-9, atol=1e-12) \
+                and np.allclose(a.covars, b.covars, rtol=1e-9, atol=1e-12) \
+                and np.allclose(a.pi, b.pi, rtol=1e-9, atol=1e-12)
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_two_rank_trainer_step_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_rank_main, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert ret.get(0) and ret.get(1)
