@@ -13,9 +13,11 @@ Differences from the reference, on purpose:
     scaled recursion (the reference's "log" forward adds ``transmat`` where it
     needs ``log(transmat)``, my_hmmlearn/utils.py:162 -- that result is wrong
     and is not reproduced).
-  * ``fit`` re-estimates means and covariances too (``mstep="full"``, the
-    ``do_mstep`` of hmm.py:165-184).  The reference's ``fit`` calls only
-    ``do_em_mstep`` (hmm.py:213); ``mstep="transitions_only"`` does exactly that.
+  * ``mstep`` chooses what ``fit`` re-estimates: "transitions_only" (default) is the
+    reference's literal behaviour -- its ``fit`` calls only ``do_em_mstep``
+    (hmm.py:213), so means and covariances stay as ``init`` drew them; "full" also
+    runs ``do_mstep`` (hmm.py:165-184, hmmlearn's diagonal M-step), which the
+    reference defines and never calls.  ``GaussianHMM`` (hmmlearn's class) is "full".
   * ``decode`` works (hmm.py:357-373 raises TypeError).
   * ``dtype="float64"`` (default) is the validation arithmetic; "float32" is
     the fast path.
@@ -75,7 +77,7 @@ class MyGaussianHMM:
     def __init__(self, n_components=1, covariance_type="diag", min_covar=1e-3,
                  startprob_prior=1.0, transmat_prior=1.0, means_prior=0, means_weight=0,
                  covars_prior=1e-2, covars_weight=1, random_state=None, n_iter=10, tol=1e-2,
-                 verbose=True, implementation="log", *, mstep="full", dtype="float64",
+                 verbose=True, implementation="log", *, mstep="transitions_only", dtype="float64",
                  device=None):
         if covariance_type != "diag":
             raise ValueError("only covariance_type='diag' is implemented")
@@ -290,18 +292,38 @@ class MyGaussianHMM:
     def fit_from_current(self, X, lengths=None):
         """EM iterations from the parameters the object already holds (the way
         to get runs that do not depend on the global random state)."""
+        import torch
         data = self._data(X, lengths)
         bank = self._bank()
         pri = self._priors()
         self.monitor_ = ConvergenceMonitor(self.tol, self.n_iter, self.verbose)
+        # The host never waits for the iteration it has just queued: the log-probability of
+        # iteration k travels to pinned host memory asynchronously and is looked at while
+        # iteration k + 1 runs.  If it says "converged", iteration k + 1 is one too many; its
+        # M-step is undone from the snapshot taken just before it, so the parameters and the
+        # history are the ones of the reference's loop, which checks after every iteration.
+        n_iter = int(self.n_iter)
+        logp = torch.empty((max(n_iter, 1),), dtype=torch.float64).pin_memory()
+        events = [torch.cuda.Event() for _ in range(2)]
+        snap = None
         stats = None
-        for _ in range(self.n_iter):
+        stopped = False
+        for k in range(n_iter):
             stats = bank.estep(data, out=stats)
-            logprob = float(stats[0, 1].item())
+            logp[k:k + 1].copy_(stats[0, 1:2], non_blocking=True)
+            snap = bank.snapshot(snap)                          # parameters before M-step k
             bank.mstep(stats, pri, self.mstep)
-            self.monitor_.report(logprob)
-            if self.monitor_.converged:
-                break
+            events[k % 2].record()
+            if k >= 1:
+                events[(k - 1) % 2].synchronize()
+                self.monitor_.report(float(logp[k - 1]))
+                if self.monitor_.converged:
+                    bank.restore(snap)                          # drop iteration k
+                    stopped = True
+                    break
+        if not stopped and n_iter >= 1:
+            events[(n_iter - 1) % 2].synchronize()
+            self.monitor_.report(float(logp[n_iter - 1]))
         self._pull(bank)
         if (self.transmat_.sum(axis=1) == 0).any():
             print("Some rows of transmat_ have zero sum because no transition from the state "

@@ -35,7 +35,11 @@ def extract_many(audio_paths, sample_rate, dtype="float64"):
 def train_hmm(models, audio_files, labels, sample_rate, i=-1, *, model_dir="SavedModels",
               n_components=3, tol=1e-4, n_iter=2000, save=True, verbose=True, **hmm_kw):
     """One model per distinct label, trained on that label's files and stored in
-    ``models[label]`` (and pickled), HMM_final.py:26-46."""
+    ``models[label]`` (and pickled), HMM_final.py:26-46.  Like the reference's, the
+    models are ``MyGaussianHMM(n_components=3, tol=1e-4, n_iter=2000,
+    implementation="scaling")`` and ``fit`` re-estimates start and transition
+    probabilities only; ``mstep="full"`` (and any other constructor argument, e.g.
+    ``random_state``, ``dtype``) goes through ``hmm_kw``."""
     print("Training started ...")
     labels = np.asarray(labels)
     feats, lengths = extract_many(audio_files, sample_rate, dtype=hmm_kw.get("dtype", "float64"))
@@ -78,10 +82,10 @@ def recognize_many(models, audio_paths, sample_rate, dtype="float64"):
     return [names[int(np.argmax(row))] for row in scores], scores
 
 
-def recognize(models, audio_path, sample_rate):
+def recognize(models, audio_path, sample_rate, dtype="float64"):
     """Label whose model gives the utterance the highest log-likelihood,
     HMM_final.py:49-52."""
-    return recognize_many(models, [audio_path], sample_rate)[0][0]
+    return recognize_many(models, [audio_path], sample_rate, dtype=dtype)[0][0]
 
 
 def load_models(model_dir="models"):
@@ -114,7 +118,8 @@ def _word_of(sample):
     return stem[: stem.rfind("_")]
 
 
-def test_trained_model(models, directory, sample_rate, folds_dir="Folds", lists=None):
+def test_trained_model(models, directory, sample_rate, folds_dir="Folds", lists=None,
+                       dtype="float64"):
     """Score the validation lists and print right / wrong per list,
     HMM_final.py:134-165 (fold 1 is listed twice there).  Returns the
     (right, wrong) pairs."""
@@ -125,7 +130,8 @@ def test_trained_model(models, directory, sample_rate, folds_dir="Folds", lists=
         with open(os.path.join(folds_dir, name)) as f:
             samples = [l.strip() for l in f if l.strip()]
         print(name)
-        pred, _ = recognize_many(models, [f"{directory}/{s}" for s in samples], sample_rate)
+        pred, _ = recognize_many(models, [f"{directory}/{s}" for s in samples], sample_rate,
+                                 dtype=dtype)
         right = 0
         for s, p in zip(samples, pred):
             print(_word_of(s))

@@ -155,10 +155,14 @@ class HMMBank:
         if np.any(cv <= 0):
             raise ValueError("'diag' covars must be positive")
         self.M, self.S, self.D = M, S, int(mu.shape[2])
-        self.startprob = ctx.tensor(sp)
-        self.transmat = ctx.tensor(A)
-        self.means = ctx.tensor(mu)
-        self.covars = ctx.tensor(cv)
+        # one allocation for the four arrays, so that a snapshot of the whole bank is one copy
+        flat = np.concatenate([sp.ravel(), A.ravel(), mu.ravel(), cv.ravel()])
+        self._flat = ctx.tensor(flat)
+        n = [0, sp.size, sp.size + A.size, sp.size + A.size + mu.size, flat.size]
+        self.startprob = self._flat[n[0]:n[1]].view(sp.shape)
+        self.transmat = self._flat[n[1]:n[2]].view(A.shape)
+        self.means = self._flat[n[2]:n[3]].view(mu.shape)
+        self.covars = self._flat[n[3]:n[4]].view(cv.shape)
         self._struct = _lib.Models(M, S, self.D, self.startprob.data_ptr(),
                                    self.transmat.data_ptr(), self.means.data_ptr(),
                                    self.covars.data_ptr())
@@ -266,6 +270,16 @@ class HMMBank:
                 "transitions_only": _lib.SRX_MSTEP_TRANSITIONS_ONLY}[mode]
         check(lib.srx_mstep(self.ctx.handle, ptr(stats), C.byref(pr), code, C.byref(self._struct),
                             self.ctx.stream_ptr()), "srx_mstep")
+
+    def snapshot(self, out=None):
+        """Device copy of all parameters (one launch); ``restore`` puts it back."""
+        if out is None:
+            return self._flat.clone()
+        out.copy_(self._flat)
+        return out
+
+    def restore(self, snap):
+        self._flat.copy_(snap)
 
     # -- host views --------------------------------------------------------
     def params_host(self):

@@ -2,7 +2,7 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_golden.py [mfcc] [hmm] [folds] [post] [endpoint]
+    python tests/golden/make_golden.py [mfcc] [hmm] [folds] [post] [endpoint] [harness]
 
 The reference modules are imported as they are.  ``mfcc.py`` imports three
 third-party modules that are absent here and that the code path never uses for
@@ -342,8 +342,108 @@ def make_folds(ref_final, ref_hmm, n_iter=8):
     print("folds_golden.npz written")
 
 
+HARNESS_SEED = 11          # random_state of every model train_hmm builds in make_harness
+HARNESS_GLOBAL_SEED = 77   # numpy's global generator before train_hmm (Dirichlet draws)
+
+
+def make_harness(ref_mfcc, ref_final, ref_hmm):
+    """The HMM_final.py call surface end to end on the 24 fold-1 validation recordings,
+    stored as float32 WAVs in a scratch directory the reference's functions are run in:
+
+    * ``calculate_mfcc_for_onerecording`` / ``extract_mfcc_calc`` of every file;
+    * ``recognize`` of every file and ``test_trained_model`` (its printed text) with the
+      fold-1 models of folds_golden.npz, over six lists drawn from the 24 names;
+    * ``train_hmm`` on the 24 files (4 per word).  Its models are built with
+      ``random_state=None``, which re-seeds numpy from the clock (hmm.py:125); to get a
+      run that can be repeated the class it instantiates is swapped for a subclass that
+      differs only in passing ``random_state=HARNESS_SEED``, and numpy's global generator
+      is seeded with HARNESS_GLOBAL_SEED first (the Dirichlet draws of hmm.py:120-124 come
+      from it).  Everything else is the reference's own code: init, the EM loop of
+      ``fit`` with ``do_em_mstep`` only, the monitor's stopping rule, the pickling."""
+    import contextlib
+    import io
+    from scipy.io import wavfile
+    folds = np.load(os.path.join(OUT, "folds_golden.npz"))
+    names = [str(n) for n in folds["f1_val"]]
+    sr = 22050
+    data = {"names": np.array(names), "sr": np.int64(sr), "words": np.array(WORDS),
+            "seed": np.int64(HARNESS_SEED), "global_seed": np.int64(HARNESS_GLOBAL_SEED)}
+    rng = np.random.default_rng(99)
+    lists = [names, names] + [[names[i] for i in rng.permutation(24)[:n]] for n in (24, 17, 12, 20)]
+    list_files = ["validation 1.txt", "validation 1.txt", "validation 2.txt", "validation 3.txt",
+                  "validation 4.txt", "validation 5.txt"]
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "wav"))
+        os.makedirs(os.path.join(tmp, "Folds"))
+        os.makedirs(os.path.join(tmp, "SavedModels"))
+        for fname, lst in zip(list_files[1:], lists[1:]):
+            with open(os.path.join(tmp, "Folds", fname), "w") as f:
+                f.write("".join(n + ".wav\n" for n in lst))
+        for k, lst in enumerate(lists[1:]):
+            data[f"list{k + 1}"] = np.array(lst)
+        os.chdir(tmp)
+        try:
+            sigs, feats, zs = [], [], []
+            for n in names:
+                s = wavfile.read(f"{REF}/cleaned_audios_3005/{n}.wav")[1]
+                s32 = np.asarray(s, dtype=np.float32)
+                wavfile.write(f"wav/{n}.wav", sr, s32)
+                sigs.append(s32)
+                feats.append(ref_mfcc.calculate_mfcc_for_onerecording(False, f"wav/{n}.wav", sample_rate=sr))
+                zs.append(ref_final.extract_mfcc_calc(f"wav/{n}.wav", sr))
+            data["sig_lengths"] = np.array([len(x) for x in sigs])
+            data["signals"] = np.concatenate(sigs)
+            data["lengths"] = np.array([len(z) for z in zs])
+            data["feat"] = np.concatenate([f.T for f in feats])      # (sum T, 26), rows = frames
+            data["z"] = np.concatenate(zs)                           # (sum T, 26)
+            models = {}
+            for w in WORDS:
+                p = f"f1_{w}_"
+                models[w] = _ref_model(ref_hmm, folds[p + "pi"], folds[p + "A"], folds[p + "mu"], folds[p + "var"])
+            data["labels"] = np.array([ref_final.recognize(models, f"wav/{n}.wav", sr) for n in names])
+            data["scores"] = np.array([[models[w].score(z) for w in WORDS] for z in zs])
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                ref_final.test_trained_model(models, "wav", sr)
+            data["test_trained_model_stdout"] = np.array(buf.getvalue())
+            print(buf.getvalue().count("right:"), "lists;", [l for l in buf.getvalue().splitlines() if l.startswith("right")])
+            # seeded train_hmm
+            plain = ref_hmm.MyGaussianHMM
+            seeded = type("SeededHMM", (plain,), {
+                "__init__": lambda self, **kw: plain.__init__(
+                    self, **dict(kw, random_state=HARNESS_SEED, verbose=False)),
+                "__module__": __name__, "__qualname__": "SeededHMM"})
+            globals()["SeededHMM"] = seeded
+            ref_hmm.MyGaussianHMM = seeded
+            try:
+                np.random.seed(HARNESS_GLOBAL_SEED)
+                trained = {}
+                files = [f"wav/{n}.wav" for n in names]
+                labels = [n[: n.rfind("_")] for n in names]
+                with contextlib.redirect_stdout(io.StringIO()) as tbuf:
+                    ref_final.train_hmm(trained, files, labels, sr)
+            finally:
+                ref_hmm.MyGaussianHMM = plain
+            data["train_stdout"] = np.array(tbuf.getvalue())
+            data["train_files"] = np.array(sorted(os.listdir("SavedModels")))
+            data["train_order"] = np.array(list(trained))
+            for w, m in trained.items():
+                p = f"train_{w}_"
+                data[p + "pi"], data[p + "A"] = m.startprob_, m.transmat_
+                data[p + "mu"], data[p + "var"] = m.means_, m._covars_
+                data[p + "hist"] = np.array(m.monitor_.history)
+                data[p + "iter"] = np.int64(m.monitor_.iter)
+                data[p + "score"] = np.array([m.score(z) for z in zs])
+                print(w, "iterations", m.monitor_.iter, "logprob", m.monitor_.history[-1])
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(OUT, "harness_golden.npz"), **data)
+    print("harness_golden.npz written")
+
+
 if __name__ == "__main__":
-    what = set(sys.argv[1:]) or {"mfcc", "hmm", "folds", "post", "endpoint"}
+    what = set(sys.argv[1:]) or {"mfcc", "hmm", "folds", "post", "endpoint", "harness"}
     ref_mfcc, ref_final, ref_hmm, ref_utils = _import_reference()
     if "mfcc" in what:
         make_mfcc(ref_mfcc, ref_final)
@@ -355,3 +455,5 @@ if __name__ == "__main__":
         make_endpoint()
     if "folds" in what:
         make_folds(ref_final, ref_hmm)
+    if "harness" in what:
+        make_harness(ref_mfcc, ref_final, ref_hmm)

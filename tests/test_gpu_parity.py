@@ -281,7 +281,7 @@ def test_mfcc_long_utterances(sra, ctx, seconds, delta_order, zscore):
 def test_class_surface_and_errors(sra, ctx, hmm_golden):
     g, p = hmm_golden, "s3d26_"
     m = sra.MyGaussianHMM(n_components=3, tol=1e-4, n_iter=2, implementation="scaling",
-                          verbose=False)
+                          verbose=False, mstep="full")
     m.startprob_, m.transmat_ = g[p + "pi"].copy(), g[p + "A"].copy()
     m.means_, m._covars_ = g[p + "mu"].copy(), g[p + "var"].copy()
     X, L = g[p + "X"], g[p + "lengths"]

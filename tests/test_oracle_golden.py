@@ -218,3 +218,74 @@ def test_librosa_restatement_invariants():
     np.testing.assert_allclose(sra.runtime.filterbank_host(2048, 22050, 128, "slaney"), fb, atol=1e-15)
     np.testing.assert_allclose(sra.runtime.filterbank_host(1024, 16000, 40, "slaney"),
                                mo.slaney_filterbank(16000, 1024, 40), atol=1e-15)
+
+
+def test_oracles_match_reference_harness_run():
+    """The 24 recordings the end-to-end GPU test uses: the front-end oracle reproduces the
+    reference's per-file features, the HMM oracle its 24 x 6 scores and labels, and a
+    transitions-only EM from the stored initial parameters its training histories."""
+    import os
+    from conftest import GOLDEN
+    hg = np.load(os.path.join(GOLDEN, "harness_golden.npz"))
+    fg = np.load(os.path.join(GOLDEN, "folds_golden.npz"))
+    cfg = mo.MfccConfig(sample_rate=int(hg["sr"]))
+    so = np.concatenate([[0], np.cumsum(hg["sig_lengths"])])
+    fo = np.concatenate([[0], np.cumsum(hg["lengths"])])
+    for i in range(0, 24, 3):
+        sig = hg["signals"][so[i]:so[i + 1]].astype(np.float64)
+        np.testing.assert_allclose(mo.features(sig, cfg), hg["feat"][fo[i]:fo[i + 1]], rtol=0,
+                                   atol=1e-9 * np.abs(hg["feat"]).max())
+        np.testing.assert_allclose(mo.extract(sig, cfg), hg["z"][fo[i]:fo[i + 1]], rtol=0, atol=1e-8)
+    words = [str(w) for w in hg["words"]]
+    prm = [ho.Params(fg[f"f1_{w}_pi"], fg[f"f1_{w}_A"], fg[f"f1_{w}_mu"], fg[f"f1_{w}_var"]) for w in words]
+    sc = np.stack([ho.score(p, hg["z"], hg["lengths"], loops=False) for p in prm], axis=1)
+    np.testing.assert_allclose(sc, hg["scores"], rtol=1e-10)
+    assert [words[int(np.argmax(r))] for r in sc] == [str(l) for l in hg["labels"]]
+    # training: from the trained transition rows back to the history is not possible, but the
+    # last history entry is the log-probability under the parameters before the last update,
+    # and the stored means / covariances never move: score the final model instead
+    names = [str(n) for n in hg["names"]]
+    for w in words:
+        p = ho.Params(hg[f"train_{w}_pi"], hg[f"train_{w}_A"], hg[f"train_{w}_mu"], hg[f"train_{w}_var"])
+        got = ho.score(p, hg["z"], hg["lengths"], loops=False)
+        np.testing.assert_allclose(got, hg[f"train_{w}_score"], rtol=1e-10)
+        idx = [i for i, n in enumerate(names) if n[: n.rfind("_")] == w]
+        total = float(np.sum(got[idx]))
+        hist = hg[f"train_{w}_hist"]
+        assert total >= hist[-1] - 1e-6 * abs(hist[-1])     # EM never lowers the likelihood
+
+
+def test_oracle_fit_replays_reference_training():
+    """init (my_hmmlearn/hmm.py:116-134) and the fit loop (hmm.py:198-222, do_em_mstep only)
+    restated with the oracle's E-step: the same seeds give the reference's training histories,
+    iteration counts and parameters for the six word models of the harness fixture."""
+    import os
+    from conftest import GOLDEN
+    hg = np.load(os.path.join(GOLDEN, "harness_golden.npz"))
+    names = [str(n) for n in hg["names"]]
+    fo = np.concatenate([[0], np.cumsum(hg["lengths"])])
+    np.random.seed(int(hg["global_seed"]))
+    for w in [str(x) for x in hg["train_order"]]:
+        idx = [i for i, n in enumerate(names) if n[: n.rfind("_")] == w]
+        X = np.vstack([hg["z"][fo[i]:fo[i + 1]] for i in idx])
+        L = [int(hg["lengths"][i]) for i in idx]
+        S = 3
+        rs = np.random.mtrand._rand
+        pi = rs.dirichlet(np.full(S, 1.0 / S))
+        A = rs.dirichlet(np.full(S, 1.0 / S), size=S)
+        np.random.seed(int(hg["seed"]))
+        rows = np.random.choice(X.shape[0], S, replace=False)
+        var = np.tile(np.diag(np.cov(X.T) + 1e-3 * np.eye(X.shape[1])), (S, 1))
+        p = ho.Params(pi, A, X[rows], var)
+        hist = []
+        for _ in range(2000):
+            st, lps = ho.estep(p, X, L, loops=False)
+            p = ho.mstep_transitions(p, st)
+            hist.append(float(np.sum(lps)))
+            if len(hist) >= 2 and hist[-1] - hist[-2] < 1e-4:
+                break
+        assert len(hist) == int(hg[f"train_{w}_iter"]), w
+        np.testing.assert_allclose(hist, hg[f"train_{w}_hist"], rtol=1e-11)
+        np.testing.assert_allclose(p.A, hg[f"train_{w}_A"], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(p.pi, hg[f"train_{w}_pi"], rtol=1e-9, atol=1e-13)
+        np.testing.assert_array_equal(p.means, hg[f"train_{w}_mu"])
