@@ -16,6 +16,7 @@ log-likelihoods, 2e-5 on statistics)."""
 import numpy as np
 import pytest
 
+from conftest import assert_ties_only
 from oracle import hmm_oracle as ho
 
 pytestmark = pytest.mark.gpu
@@ -157,12 +158,17 @@ def test_viterbi_full_size_properties(sra, ctx):
     assert bool((lp <= own + 1e-6 * own.abs()).all())
     assert int(path.min()) >= 0 and int(path.max()) < S
     pick = rng.choice(U, size=16, replace=False)
+    n_diff = 0
     for u in pick:
         xu = X[u * T:(u + 1) * T].cpu().numpy().astype(np.float64)
         rlp, rpath = ho.viterbi(prms[um[u]], xu, [T])
         got = path[u * T:(u + 1) * T].cpu().numpy()
         assert abs(float(lp[u]) - rlp[0]) < 1e-5 * abs(rlp[0])
-        assert np.mean(got == rpath) > 0.97
+        pu = prms[um[u]]
+        nd, _, _ = assert_ties_only(pu.pi, pu.A, ho.log_density_diag(xu, pu.means, pu.covars), [T],
+                                    got, rpath, rlp)
+        n_diff += nd
+    print(f"full-size viterbi float32: {n_diff} of {16 * T} sampled frames differ, all at ties")
 
 
 def test_posteriors_full_size_properties(sra, ctx):
@@ -287,3 +293,76 @@ def test_addressing_beyond_4gib(sra, ctx):
     ll = bank8.emission_loglik(tail)
     ll_all_tail = bank8.emission_loglik(data)[(U - n) * T:]
     assert torch.equal(ll, ll_all_tail)
+
+
+def test_training_config_full_size(sra, ctx):
+    """The training configuration at its full size on one GPU: 1,048,576 utterances x 200
+    frames x 39 dims (31 GB of features), 6 models x 16 states.
+
+    * counting identities of every model's statistics record;
+    * the first 96 utterances agree with the oracle's E-step (per model, 2e-5);
+    * addressing beyond 4 GiB: scores of the last 4096 utterances equal those of the same
+      utterances scored on their own, bit for bit, and the statistics of (everything but the
+      tail) + (the tail) add up to the statistics of the whole (the data-parallel identity
+      across the 4 GiB boundary)."""
+    import torch
+    U, T, D, M, S = 1 << 20, 200, 39, 6, 16
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * 2 ** 30:
+        pytest.skip("needs 60 GiB of free device memory")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1)
+    X = torch.empty((U * T, D), device="cuda", dtype=torch.float32)
+    for i in range(0, U * T, 1 << 24):
+        X[i:i + (1 << 24)].normal_(generator=g)
+    off = torch.arange(0, (U + 1) * T, T, device="cuda", dtype=torch.int64)
+    data = sra.Ragged(ctx, X, offsets=off, dtype="float32")
+    rng = np.random.default_rng(8)
+    prms = _models(rng, M, S, D)
+    bank = _bank(sra, ctx, prms)
+    um = (np.arange(U) % M).astype(np.int32)
+    umd = ctx.tensor(um)
+    order = ctx.tensor(np.argsort(um, kind="stable").astype(np.int64))
+    s_all = bank.estep(data, umd, order).clone()
+    st = bank.unpack_stats(s_all)
+    for m in range(M):
+        n_u = int((um == m).sum())
+        n_fr = float(n_u) * T
+        assert st[m]["nobs"] == n_u
+        assert abs(st[m]["start"].sum() - n_u) < 2e-5 * n_u
+        assert abs(st[m]["post"].sum() - n_fr) < 2e-5 * n_fr
+        assert abs(st[m]["trans"].sum() - (n_fr - n_u)) < 2e-5 * n_fr
+        assert np.isfinite(st[m]["logprob"])
+    # oracle prefix
+    n0 = 96
+    Xh = X[:n0 * T].cpu().numpy().astype(np.float64)
+    head = sra.Ragged(ctx, X[:n0 * T], offsets=off[:n0 + 1], dtype="float32")
+    sh = bank.unpack_stats(bank.estep(head, ctx.tensor(um[:n0]), None))
+    for m in range(M):
+        idx = [u for u in range(n0) if um[u] == m]
+        Xm = np.vstack([Xh[u * T:(u + 1) * T] for u in idx])
+        ref, lps = ho.estep(prms[m], Xm, [T] * len(idx), loops=False)
+        assert abs(sh[m]["logprob"] - lps.sum()) < 1e-4 * abs(lps.sum())
+        for key in ("start", "trans", "post", "obs", "obs**2"):
+            scale = np.abs(ref[key]).max()
+            assert np.max(np.abs(sh[m][key] - ref[key])) < 2e-5 * scale, (m, key)
+    # the far end of the buffer (beyond byte 4 GiB)
+    n = 4096
+    tail = sra.Ragged(ctx, X[(U - n) * T:], offsets=off[:n + 1], dtype="float32")
+    rest = sra.Ragged(ctx, X[:(U - n) * T], offsets=off[:U - n + 1], dtype="float32")
+    prm8 = _models(rng, M, 8, D)
+    bank8 = _bank(sra, ctx, prm8)
+    sc_all = bank8.score(data)
+    sc_tail = bank8.score(tail)
+    assert bool(torch.isfinite(sc_all).all())
+    assert torch.equal(sc_all[U - n:], sc_tail), "scores of the far end differ"
+    ref_sc = np.stack([ho.score(p, X[(U - 3) * T:].cpu().numpy().astype(np.float64), [T] * 3, loops=False)
+                       for p in prm8], axis=1)
+    assert np.max(np.abs(sc_all[U - 3:].cpu().numpy() - ref_sc) / np.abs(ref_sc)) < 1e-4
+    s_rest = bank.estep(rest, ctx.tensor(um[:U - n]), None).cpu().numpy()
+    s_tail = bank.estep(tail, ctx.tensor(um[U - n:]), None).cpu().numpy()
+    s_all2 = bank.estep(data, umd, None).cpu().numpy()
+    err = np.abs(s_all2 - (s_rest + s_tail)).max() / np.abs(s_all2).max()
+    assert err < 1e-6, err
+    del X, data, tail, rest
+    torch.cuda.empty_cache()

@@ -8,7 +8,7 @@ they can be arbitrarily small)."""
 import numpy as np
 import pytest
 
-from conftest import golden_params
+from conftest import assert_ties_only, golden_params
 from oracle import hmm_oracle as ho
 from oracle import mfcc_oracle as mo
 
@@ -124,8 +124,10 @@ def test_viterbi_paths_bit_exact(sra, ctx, hmm_golden, case):
     # float32: ties excepted -- a differing frame must be a near-tie
     data32 = sra.Ragged(ctx, g[p + "X"], g[p + "lengths"], dtype="float32")
     lp32, path32 = bank.viterbi(data32)
-    agree = np.mean(path32.cpu().numpy() == g[p + "vit_path"])
-    assert agree > 0.98
+    n_diff, gap, short = assert_ties_only(prm.pi, prm.A, g[p + "loglik"], g[p + "lengths"],
+                                          path32.cpu().numpy(), g[p + "vit_path"], g[p + "vit_logprob"])
+    print(f"viterbi float32 {case}: {n_diff} of {len(g[p + 'vit_path'])} frames differ, "
+          f"largest tie gap {gap:.2e}, largest shortfall {short:.2e}")
     assert _rel(lp32.cpu().numpy(), g[p + "vit_logprob"]) < 1e-5
 
 
@@ -196,18 +198,34 @@ def test_estep_order_independent(sra, ctx):
 def test_mfcc_matches_reference(sra, ctx, mfcc_golden, i):
     g = mfcc_golden
     sig, sr = g[f"sig{i}"], int(g[f"sr{i}"])
-    scale = np.abs(g[f"cep{i}"]).max()
+    # Error measure for un-normalised cepstra: |got - ref| over the RMS of that coefficient
+    # (a column of cep, a row of feat) across the utterance, so that c0 ~ -680 does not set the
+    # scale for coefficients of size 1..30.  Columns that are numerically zero in the
+    # reference (RMS below 1e-6 of the largest value: the higher cepstra and the deltas of an
+    # all-zero signal, pure rounding noise of the DCT of a constant vector) have no scale of
+    # their own and are measured against the largest value instead.
+    def row_err(got, ref):
+        if not ref.size:
+            return 0.0
+        rms = np.sqrt(np.mean(ref ** 2, axis=0, keepdims=True))
+        top = np.abs(ref).max()
+        return float(np.max(np.abs(got - ref) / np.where(rms > 1e-6 * top, rms, max(top, 1e-300))))
+
     for dtype, tol in (("float64", 1e-9), ("float32", 1e-4)):
         cep = sra.mfcc.compute_mfcc(sig, sr, dtype=dtype)
         assert cep.shape == g[f"cep{i}"].shape
-        np.testing.assert_allclose(cep, g[f"cep{i}"], rtol=tol, atol=tol * scale)
+        e_cep = row_err(cep, g[f"cep{i}"])
         f, lens = sra.mfcc.extract_batch([sig], sr, zscore=False, dtype=dtype)
         assert f.shape == g[f"feat{i}"].T.shape
-        np.testing.assert_allclose(f, g[f"feat{i}"].T, rtol=tol, atol=tol * scale)
+        e_feat = row_err(f, g[f"feat{i}"].T)
         z = sra.mfcc.extract_features(sig, sr, dtype=dtype)
         assert z.shape == g[f"z{i}"].shape
-        # z-scored features are O(1): absolute tolerance
-        np.testing.assert_allclose(z, g[f"z{i}"], rtol=0, atol=1e-7 if dtype == "float64" else 2e-3)
+        # z-scored features are O(1): absolute error (measured on MI355X: <= 1.4e-5 in float32)
+        e_z = float(np.max(np.abs(z - g[f"z{i}"]))) if z.size else 0.0
+        print(f"mfcc sig{i} {dtype}: cepstra {e_cep:.2e}, features {e_feat:.2e} of row RMS; "
+              f"z-scored {e_z:.2e} absolute")
+        assert e_cep < tol and e_feat < tol
+        assert e_z < (1e-7 if dtype == "float64" else 1e-4)
 
 
 def test_mfcc_batch_ragged_equals_single(sra, ctx, mfcc_golden):
