@@ -2,6 +2,7 @@
 #include "srx_internal.h"
 
 #include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -159,21 +160,32 @@ typedef const char* (*nccl_errstr_fn)(int);
 nccl_allreduce_fn g_allreduce = nullptr;
 nccl_errstr_fn g_errstr = nullptr;
 
+std::once_flag g_rccl_once;
+int g_rccl_rc = SRX_OK;
+char g_rccl_msg[256] = "";
+
+int bind_rccl_once();
 int bind_rccl() {
-    if (g_allreduce) return SRX_OK;
+    std::call_once(g_rccl_once, [] { g_rccl_rc = bind_rccl_once(); });
+    if (g_rccl_rc) srx_set_error("%s", g_rccl_msg);
+    return g_rccl_rc;
+}
+
+int bind_rccl_once() {
     void* lib = nullptr;
     const char* names[] = {"librccl.so", "librccl.so.1"};
     for (const char* n : names)
         if (!lib) lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // the copy already in the process
     if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!lib) {
-        srx_set_error("srx_allreduce_stats: no RCCL library (%s)", dlerror());
+        snprintf(g_rccl_msg, sizeof(g_rccl_msg), "srx_allreduce_stats: no RCCL library (%s)", dlerror());
         return SRX_EUNSUPPORTED;
     }
     g_errstr = (nccl_errstr_fn)dlsym(lib, "ncclGetErrorString");
     nccl_allreduce_fn f = (nccl_allreduce_fn)dlsym(lib, "ncclAllReduce");
     if (!f) {
-        srx_set_error("srx_allreduce_stats: ncclAllReduce not found in the RCCL library");
+        snprintf(g_rccl_msg, sizeof(g_rccl_msg),
+                 "srx_allreduce_stats: ncclAllReduce not found in the RCCL library");
         return SRX_EUNSUPPORTED;
     }
     g_allreduce = f;
@@ -189,7 +201,9 @@ int srx_allreduce_stats(srx_handle_t h, void* nccl_comm, double* stats, int64_t 
     int rc = bind_rccl();
     if (rc) return rc;
     SRX_HIP(hipSetDevice(h->device));
-    const int kNcclDouble = 8, kNcclSum = 0;                     // ncclFloat64, ncclSum (nccl.h)
+    // the codes of the RCCL this image ships (rccl/rccl.h; only the two enumerators are
+    // taken from the header, the library itself is bound at run time)
+    const int kNcclDouble = (int)ncclFloat64, kNcclSum = (int)ncclSum;
     const int res = g_allreduce(stats, stats, (size_t)count, kNcclDouble, kNcclSum, nccl_comm,
                                 (hipStream_t)stream);
     if (res != 0) {

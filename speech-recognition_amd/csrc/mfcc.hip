@@ -781,15 +781,10 @@ int64_t srx_mfcc_out_frames(const srx_mfcc_cfg_t* c, int64_t n_samples) {
     return t > 2 * c->delta_n ? t - 2 * c->delta_n : 0;
 }
 
-int srx_mfcc_plan_create(srx_handle_t h, const srx_mfcc_cfg_t* cfg, srx_mfcc_plan_t* out) {
-    SRX_REQUIRE(h != nullptr && out != nullptr, "srx_mfcc_plan_create: NULL argument");
-    int rc = check_cfg(cfg);
-    if (rc) return rc;
-    SRX_HIP(hipSetDevice(h->device));
-    srx_mfcc_plan* p = new srx_mfcc_plan();
-    memset(p, 0, sizeof(*p));
-    p->ctx = h;
-    p->cfg = *cfg;
+// Builds the tables of a zero-initialised plan; on failure the caller destroys the plan
+// with whatever tables it already holds.
+static int plan_fill(srx_mfcc_plan* p, const srx_mfcc_cfg_t* cfg) {
+    int rc = SRX_OK;
     int l2 = 0;
     while ((1 << l2) < cfg->nfft) ++l2;
     p->log2n = l2;
@@ -939,6 +934,26 @@ int srx_mfcc_plan_create(srx_handle_t h, const srx_mfcc_cfg_t* cfg, srx_mfcc_pla
     SRX_HIP(hipMemcpy(p->mel_bin, bins.data(), sizeof(int32_t) * bins.size(), hipMemcpyHostToDevice));
     SRX_HIP(hipMalloc((void**)&p->mel_ptr, sizeof(int32_t) * ptr.size()));
     SRX_HIP(hipMemcpy(p->mel_ptr, ptr.data(), sizeof(int32_t) * ptr.size(), hipMemcpyHostToDevice));
+    return SRX_OK;
+}
+
+int srx_mfcc_plan_destroy(srx_mfcc_plan_t p);
+
+int srx_mfcc_plan_create(srx_handle_t h, const srx_mfcc_cfg_t* cfg, srx_mfcc_plan_t* out) {
+    SRX_REQUIRE(h != nullptr && out != nullptr, "srx_mfcc_plan_create: NULL argument");
+    *out = nullptr;
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    SRX_HIP(hipSetDevice(h->device));
+    srx_mfcc_plan* p = new srx_mfcc_plan();
+    memset(p, 0, sizeof(*p));
+    p->ctx = h;
+    p->cfg = *cfg;
+    rc = plan_fill(p, cfg);
+    if (rc) {
+        srx_mfcc_plan_destroy(p);      // frees the tables made so far; the message stays
+        return rc;
+    }
     *out = p;
     return SRX_OK;
 }

@@ -15,10 +15,17 @@ _plans = {}
 
 
 def _plan(ctx, sample_rate, **kw):
-    key = (ctx.index, int(sample_rate)) + tuple(sorted(kw.items()))
+    key = (id(ctx), int(sample_rate)) + tuple(sorted(kw.items()))
     if key not in _plans:
         _plans[key] = MfccPlan(ctx, sample_rate, **kw)
     return _plans[key]
+
+
+def drop_plans(ctx):
+    """Destroy the cached plans of a context (called by Context.close: a plan is bound to
+    the context it was made with)."""
+    for key in [k for k, p in _plans.items() if p.ctx is ctx]:
+        _plans.pop(key).close()
 
 
 def mel_filterbank(NFFT, sample_rate=16000, num_filters=26):
@@ -78,7 +85,7 @@ def librosa_mfcc_batch(signals, sample_rate, n_mfcc=13, *, zscore=False, dtype="
     librosa itself is not used (it is a third-party package the reference does not
     pin); this follows the published algorithm of its 0.10 line."""
     ctx = ctx or Context.default()
-    key = ("librosa", ctx.index, int(sample_rate), int(n_mfcc), bool(zscore)) + tuple(sorted(kw.items()))
+    key = ("librosa", id(ctx), int(sample_rate), int(n_mfcc), bool(zscore)) + tuple(sorted(kw.items()))
     if key not in _plans:
         _plans[key] = MfccPlan.librosa(ctx, sample_rate, n_mfcc=n_mfcc, zscore=zscore, **kw)
     lens = np.array([len(s) for s in signals], dtype=np.int64)

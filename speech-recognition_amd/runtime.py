@@ -48,12 +48,15 @@ class Context:
 
     @classmethod
     def default(cls, device=None):
+        """The process-wide context of (device, current torch stream): work queued on two
+        streams must not share one context's scratch buffers, so each stream gets its own."""
         _require_gpu()
         idx = torch.cuda.current_device() if device is None else int(device)
+        key = (idx, int(torch.cuda.current_stream(idx).cuda_stream))
         with cls._lock:
-            if idx not in cls._default:
-                cls._default[idx] = cls(idx)
-            return cls._default[idx]
+            if key not in cls._default:
+                cls._default[key] = cls(idx)
+            return cls._default[key]
 
     @property
     def handle(self):
@@ -85,8 +88,13 @@ class Context:
 
     def close(self):
         if self._h:
+            from . import mfcc as _fe
+            _fe.drop_plans(self)
             lib.srx_destroy(self._h)
             self._h = C.c_void_p()
+            with Context._lock:
+                for k in [k for k, v in Context._default.items() if v is self]:
+                    del Context._default[k]
 
 
 def ptr(t):

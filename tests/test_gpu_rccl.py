@@ -1,8 +1,10 @@
 """srx_allreduce_stats through the C ABI on a one-rank RCCL communicator (a GPU box has one
-card; RCCL refuses two ranks on one device).  Checks the binding to the RCCL copy already
-in the process, the argument order and the dtype / operator codes: the sum over one rank
-must return the statistics unchanged, on the given stream.  The two-rank arithmetic is
-covered on CPU (gloo) in tests/test_host_cpu.py."""
+card; RCCL refuses two ranks on one device).  What this pins: the library finds
+ncclAllReduce in the RCCL copy already in the process, passes communicator, buffer, count
+and stream in the right places (RCCL rejects anything else), works in place and corrupts
+nothing.  A sum over one rank is the identity for any element type and operator, so the
+dtype / operator codes are NOT checked here: they are the enumerators of rccl/rccl.h at
+build time.  The two-rank arithmetic is covered on CPU (gloo) in tests/test_host_cpu.py."""
 import ctypes as C
 import os
 
