@@ -19,18 +19,27 @@
 //      plan: weights per (quad, lane), first bin per block).  Blocks that share
 //      filters add up through LDS; log10; the DCT's 16 blocks are 4 groups of
 //      cepstra x 4 slices of the filters, added across lanes at the end.
-// A wave carries 4 frames at once, a workgroup 16 (12 in the 1024-point kernel); work
-// items are cut from the packed sample axis exactly as in the generic kernel (mfcc.hip).
+// A wave carries 4 frames at once, a workgroup 16 (12 in the 1024-point kernel).  Cepstra
+// rows live on the packed sample axis exactly as in the generic kernel (mfcc.hip): frame t
+// of an utterance that starts at sample s0 is row s0 / hop + t.  A small kernel first writes,
+// for every row, the sample its frame starts at (-1: no frame there); the transform kernel
+// then takes 16 consecutive rows per step and never looks at the utterance offsets.
 #include "srx_internal.h"
 
 #include <math.h>
+#include <stdlib.h>
+
+#ifndef SRX_FB16
+#define SRX_FB16 16
+#define SRX_WPS16 3
+#endif
 
 namespace {
 
 constexpr int kWave = 64;
 // Frames a workgroup transforms at once (4 per wave).  The 1024-point kernel takes 12:
 // two workgroups of it fit the LDS of a CU, one of 16 frames would be alone.
-template <int P> constexpr int frames_per_block() { return P == 16 ? 16 : 12; }
+template <int P> constexpr int frames_per_block() { return P == 16 ? SRX_FB16 : 12; }
 
 struct FastDev {
     int frame_len, hop, n_used, n_mel, n_ceps, nnz;
@@ -87,10 +96,39 @@ __device__ __forceinline__ v2f cmul(v2f w, v2f z) {
     return w.xx * z + wyy * z.yx;
 }
 
-// In-place radix-2 DIT on registers.  Input must already sit in bit-reversed
-// order (a[brev(n)] = x[n]); tw[q] = W_Q^q for q < Q/2.
+// The same product for operands in vector registers, as the two packed instructions it is:
+// half swaps and sign changes ride on the operand modifiers (the compiler spends an xor and a
+// move per product on building (-w.y, w.y)).
+__device__ __forceinline__ v2f cmul_v(v2f w, v2f z) {
+    v2f t, r;
+    // t = (-w.y z.y, w.y z.x)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]"
+        : "=v"(t) : "v"(w), "v"(z));
+    // r = (w.x z.x, w.x z.y) + t
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]"
+        : "=v"(r) : "v"(w), "v"(z), "v"(t));
+    return r;
+}
+
+// W_32^q = exp(-2 pi i q / 32), q < 16, rounded to float from the double values (the
+// same numbers the plan's twiddle table holds).  The register transforms take their
+// twiddles from here: compile-time constants sit in scalar registers or literals, a
+// table read at run time would cost a vector register pair per twiddle.
+__device__ constexpr float kCos32[16] = {
+    1.0f, 0.9807852506637573f, 0.9238795042037964f, 0.8314695954322815f, 0.7071067690849304f,
+    0.5555702447891235f, 0.3826834261417389f, 0.19509032368659973f, 6.123234262925839e-17f,
+    -0.19509032368659973f, -0.3826834261417389f, -0.5555702447891235f, -0.7071067690849304f,
+    -0.8314695954322815f, -0.9238795042037964f, -0.9807852506637573f};
+__device__ constexpr float kSin32[16] = {
+    -0.0f, -0.19509032368659973f, -0.3826834261417389f, -0.5555702447891235f, -0.7071067690849304f,
+    -0.8314695954322815f, -0.9238795042037964f, -0.9807852506637573f, -1.0f, -0.9807852506637573f,
+    -0.9238795042037964f, -0.8314695954322815f, -0.7071067690849304f, -0.5555702447891235f,
+    -0.3826834261417389f, -0.19509032368659973f};
+
+// In-place radix-2 DIT on registers (Q = 16 or 32).  Input must already sit in
+// bit-reversed order (a[brev(n)] = x[n]); the twiddles W_Q^q are compile-time constants.
 template <int Q>
-__device__ __forceinline__ void fft_regs(v2f (&z)[Q], const v2f (&tw)[Q / 2]) {
+__device__ __forceinline__ void fft_regs(v2f (&z)[Q]) {
 #pragma unroll
     for (int s = 1; s <= ilog2(Q); ++s) {
         const int m = 1 << s, half = m >> 1, tstep = Q / m;
@@ -102,10 +140,18 @@ __device__ __forceinline__ void fft_regs(v2f (&z)[Q], const v2f (&tw)[Q / 2]) {
                 v2f t;
                 if (jj == 0) {
                     t = z[i1];
-                } else if (2 * jj == half) {     // W = -i
-                    t = v2f{z[i1].y, -z[i1].x};
+                } else if (2 * jj == half) {     // W = -i: t = (z.y, -z.x), folded into the two adds
+                    v2f a, b;
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]"
+                        : "=v"(a) : "v"(z[i0]), "v"(z[i1]));
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]"
+                        : "=v"(b) : "v"(z[i0]), "v"(z[i1]));
+                    z[i0] = a;
+                    z[i1] = b;
+                    continue;
                 } else {
-                    t = cmul(tw[jj * tstep], z[i1]);
+                    const int q32 = jj * tstep * (32 / Q);      // folds to a constant once unrolled
+                    t = cmul(v2f{kCos32[q32], kSin32[q32]}, z[i1]);
                 }
                 z[i1] = z[i0] - t;
                 z[i0] = z[i0] + t;
@@ -118,9 +164,26 @@ __device__ __forceinline__ int64_t raw_frames(int64_t n, int L, int hop) {
     return n < L ? 0 : (n - L) / hop + 1;
 }
 
+// row_start[s0 / hop + t] = s0 + t * hop for every frame t of every utterance (one wave per
+// utterance at a time); the table is filled with -1 before.
+__global__ __launch_bounds__(256) void row_start_kernel(const int64_t* __restrict__ so, int64_t U,
+                                                        int frame_len, unsigned hop, unsigned hop_m,
+                                                        unsigned hop_s, int32_t* __restrict__ row_start) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t u = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); u < U; u += n_waves) {
+        const int64_t us = so[u];
+        const unsigned n = (unsigned)(so[u + 1] - us);
+        if (n < (unsigned)frame_len) continue;
+        const unsigned T = (__umulhi(n - (unsigned)frame_len, hop_m) >> hop_s) + 1u;
+        const unsigned row0 = __umulhi((unsigned)us, hop_m) >> hop_s;
+        for (unsigned t = lane; t < T; t += 64) row_start[row0 + t] = (int32_t)((unsigned)us + t * hop);
+    }
+}
+
 template <int P>
-__global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_fast_kernel(
-    const float* __restrict__ audio, const int64_t* __restrict__ so, int64_t U, int64_t total,
+__global__ __launch_bounds__(P == 16 ? 16 * SRX_FB16 : 192, P == 16 ? SRX_WPS16 : 2) void cepstra_fast_kernel(
+    const float* __restrict__ audio, const int32_t* __restrict__ row_start, int64_t n_rows, int64_t total,
     FastDev c, float* __restrict__ cep) {
     constexpr int H = 16 * P, N = 2 * H, KB = P / 16;   // KB 16-point FFTs per lane in step 3
     constexpr int YS = P * 17;                          // float2 per frame in the transpose tile
@@ -170,74 +233,22 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
     const int grp_first = s_meta[16 + blk], grp_cnt = s_meta[32 + blk];   // (lane as (group, column))
     const int ks = lane >> 4, cg = (lane >> 2) & 3;   // DCT: slice of filters, group of cepstra
 
-    // twiddles of the register FFTs: W_P^q (first pass) and W_16^q (second pass)
-    v2f twp[P / 2], tw16[8];
-#pragma unroll
-    for (int q = 0; q < P / 2; ++q) twp[q] = v2f{c.tw[q * (N / P)].x, c.tw[q * (N / P)].y};
-#pragma unroll
-    for (int q = 0; q < 8; ++q) tw16[q] = v2f{c.tw[q * (N / 16)].x, c.tw[q * (N / 16)].y};
-
-    // A workgroup walks a CONTIGUOUS range of chunks: the utterance under its
-    // position then advances monotonically (offsets cached in registers, no search
-    // per chunk), and the samples of chunk b+1 are requested before chunk b is
-    // transformed, so neither the offset lookups nor the sample loads stall it.
-    const int64_t chunk = (int64_t)frames_per_block<P>() * c.hop;
-    const int64_t n_chunks = (total + chunk - 1) / chunk;
+    // A workgroup walks a CONTIGUOUS range of steps of FB rows each.  The start sample of a
+    // row is read two steps ahead and the samples of step b+1 are requested before step b is
+    // transformed, so neither load is waited for where it is issued.
+    constexpr int FB = frames_per_block<P>();
+    const int64_t n_chunks = (n_rows + FB - 1) / FB;
     const int64_t per_block = (n_chunks + gridDim.x - 1) / gridDim.x;
     const int64_t b_begin = (int64_t)blockIdx.x * per_block;
     const int64_t b_end = b_begin + per_block < n_chunks ? b_begin + per_block : n_chunks;
     if (b_begin >= b_end) return;
-    int64_t lo = 0;
-    {
-        int64_t hi = U;
-        const int64_t p0 = b_begin * chunk;
-        while (hi - lo > 1) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (so[mid] <= p0) lo = mid; else hi = mid;
-        }
-    }
-    int64_t so_lo = so[lo], so_nx = so[lo + 1];
     const unsigned hop = (unsigned)c.hop;
-    // division by the hop as a multiplication (exact below 2^31; the values are
-    // wave-uniform, so this stays on the scalar unit)
-    auto div_hop = [&](unsigned n) { return __umulhi(n, c.hop_m) >> c.hop_s; };
-    struct Loc {
-        bool have;
-        int64_t s0;
-        unsigned t, row0;
-    };
-    // which frame does this lane group own?  (item-th frame starting in [p0, p1))
-    // The packed buffer holds < 2^31 samples here: 32-bit arithmetic is enough.
-    auto locate = [&](int64_t bq) {
-        const int64_t p0 = bq * chunk;
-        const int64_t p1 = p0 + chunk < total ? p0 + chunk : total;
-        while (lo + 1 < U && so_nx <= p0) {      // wave-uniform
-            ++lo;
-            so_lo = so_nx;
-            so_nx = so[lo + 1];
-        }
-        Loc r{false, 0, 0u, 0u};
-        int cnt = 0;
-        int64_t us = so_lo, ue = so_nx;
-        for (int64_t u = lo; u < U && us < p1 && !r.have; ++u) {
-            const unsigned n = (unsigned)(ue - us);
-            const unsigned Tu = n < (unsigned)c.frame_len ? 0u : div_hop(n - (unsigned)c.frame_len) + 1u;
-            const unsigned a = p0 > us ? (unsigned)(p0 - us) : 0u;
-            const unsigned ta = div_hop(a + hop - 1u);
-            unsigned tb = div_hop((unsigned)(p1 - us) + hop - 1u);
-            if (tb > Tu) tb = Tu;
-            const int nn = tb > ta ? (int)(tb - ta) : 0;
-            if (item < cnt + nn) {
-                r.have = true;
-                r.s0 = us;
-                r.t = ta + (unsigned)(item - cnt);
-                r.row0 = div_hop((unsigned)us);
-            }
-            cnt += nn;
-            us = ue;
-            if (u + 2 <= U && us < p1 && !r.have) ue = so[u + 2];
-        }
-        return r;
+    // start sample of this lane group's row in step bq (-1: none)
+    auto row_of = [&](int64_t bq) { return bq * FB + item; };
+    auto load_start = [&](int64_t bq) -> int {
+        const int64_t r = row_of(bq);
+        const int v = row_start[r < n_rows ? r : n_rows - 1];
+        return r < n_rows ? v : -1;
     };
     // Sample loads are raw buffer loads on a per-chunk descriptor that ends with the
     // packed buffer (a frame's 8-byte pairs are only 4-byte aligned; past the end the
@@ -246,8 +257,9 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
     // multiplication whose zero wins over anything (fmul_legacy), so a frame never
     // sees its neighbour's samples.  A group without a frame reads the chunk's first
     // samples and stores nothing.
-    auto fetch = [&](const Loc& l, int64_t bq, float (&xr)[2 * P]) {
-        const int64_t p0 = bq * chunk;
+    auto fetch = [&](int start, int64_t bq, float (&xr)[2 * P]) {
+        // rows of step bq start at samples >= bq * FB * hop
+        const int64_t p0 = bq * FB * (int64_t)hop < total ? bq * FB * (int64_t)hop : 0;
         const uintptr_t a = (uintptr_t)(audio + p0);
         const int64_t rest = (total - p0) * 4;
         const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)a);
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
         const unsigned nrec = __builtin_amdgcn_readfirstlane((unsigned)(rest < 0xFFFFFF00ll ? rest : 0xFFFFFF00ll));
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(((uintptr_t)hi32 << 32) | lo32), 0, nrec, 0x00020000);
-        const unsigned rel = l.have ? (unsigned)(l.s0 - p0) + l.t * hop : 0u;
+        const unsigned rel = start >= 0 ? (unsigned)start - (unsigned)p0 : 0u;
         const unsigned voff = (rel + 2u * (unsigned)j) * 4u;
 #pragma unroll
         for (int n1 = 0; n1 < P; ++n1) {
@@ -264,16 +276,9 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
             xr[2 * n1 + 1] = __uint_as_float(v[1]);
         }
     };
-    Loc cur = locate(b_begin);
-    float xc[2 * P];
-    fetch(cur, b_begin, xc);
-    for (int64_t b = b_begin; b < b_end; ++b) {
-        Loc nxt = cur;
-        float xn[2 * P];
-        if (b + 1 < b_end) nxt = locate(b + 1);
-        fetch(nxt, b + 1 < b_end ? b + 1 : b, xn);   // (the last chunk's repeat is harmless)
-        const bool have = cur.have;
-        const unsigned t = cur.t, row0 = cur.row0;
+    // one step: the frames whose samples are in xc (start sample `start`, row `row`)
+    auto transform = [&](int start, int64_t row, const float (&xc)[2 * P]) {
+        const bool have = start >= 0;
         // ---- 1. window, bit-reversed register order, P-point FFT over n1
         const bool any = __ballot(have) != 0;     // no frame starts in this chunk for this wave?
         v2f z1[P];
@@ -284,10 +289,10 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
             z1[brev(n1, ilog2(P))] = v2f{mul_zero_wins(xc[2 * n1], wv.x), mul_zero_wins(xc[2 * n1 + 1], wv.y)};
         }
         if (any) {
-        fft_regs<P>(z1, twp);
+        fft_regs<P>(z1);
         // ---- 2. twiddle W_H^(j k1) and 3. transpose through LDS: Y[k1][j]
 #pragma unroll
-        for (int k1 = 0; k1 < P; ++k1) Y[k1 * 17 + j] = cmul(s_tw2[k1 * 16 + j], z1[k1]);
+        for (int k1 = 0; k1 < P; ++k1) Y[k1 * 17 + j] = cmul_v(s_tw2[k1 * 16 + j], z1[k1]);
         wave_sync();
         v2f z2[KB][16];
 #pragma unroll
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
         wave_sync();
 #pragma unroll
         for (int i = 0; i < KB; ++i) {
-            fft_regs<16>(z2[i], tw16);
+            fft_regs<16>(z2[i]);
             // Z[k1 + P k2] in natural order over the same LDS region
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) Y[j + 16 * i + P * k2] = z2[i][k2];
@@ -322,10 +327,15 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
             // with E = (Z[k] + conj Z[H-k]) / 2 and O = -i (Z[k] - conj Z[H-k]) / 2:
             // X[k] = E + W^k O ;  X[H-k] = conj(E - W^k O).  The halves are left out
             // until the end (|2X|^2 / 4).
-            const v2f cc = {zcs[mm].x, -zcs[mm].y};
-            const v2f e2 = zks[mm] + cc, dd = zks[mm] - cc;
-            const v2f o2 = {dd.y, -dd.x};
-            const v2f pp = cmul(s_tw[k], o2);
+            v2f e2, dd, t1, pp;
+            // e2 = Z[k] + conj Z[H-k], dd = Z[k] - conj Z[H-k]
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(e2) : "v"(zks[mm]), "v"(zcs[mm]));
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(dd) : "v"(zks[mm]), "v"(zcs[mm]));
+            // pp = W^k (dd.y, -dd.x) = (w.x dd.y + w.y dd.x, w.y dd.y - w.x dd.x)
+            const v2f w = s_tw[k];
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t1) : "v"(w), "v"(dd));
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[0,0,0] neg_hi:[0,1,0]"
+                : "=v"(pp) : "v"(w), "v"(dd), "v"(t1));
             const v2f xa = e2 + pp, xb = e2 - pp;
             const v2f qa = xa * xa, qb = xb * xb;
             pw[k] = (qa.x + qa.y) * quarter_inv_n;
@@ -341,16 +351,25 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const float* wq = s_w4 + lane * 4;
             const float* pq = pw_col + k0;
-            // (the next quad's operands are requested before this quad's products)
-            f32x4 w = *(const f32x4*)wq, pv = *(const f32x4*)pq;
-            for (int q = 0; q < c.nq; ++q) {
-                const int qn = q + 1 < c.nq ? q + 1 : q;
-                const f32x4 wn = *(const f32x4*)(wq + qn * 256);
-                const f32x4 pn = *(const f32x4*)(pq + qn * 4);
+            // (the next quad's operands are requested before this quad's products; two quads
+            // per trip with two operand sets, so that no set is copied into the other)
+            f32x4 wa = *(const f32x4*)wq, pa = *(const f32x4*)pq, wb, pb;
+            const int nq = c.nq;
+            int q = 0;
+            for (; q + 2 <= nq; q += 2) {
+                wb = *(const f32x4*)(wq + (q + 1) * 256);
+                pb = *(const f32x4*)(pq + (q + 1) * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w[e], pv[e], acc, 0, 0, 0);
-                w = wn;
-                pv = pn;
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[e], pa[e], acc, 0, 0, 0);
+                const int q2 = q + 2 < nq ? q + 2 : q + 1;
+                wa = *(const f32x4*)(wq + q2 * 256);
+                pa = *(const f32x4*)(pq + q2 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[e], pb[e], acc, 0, 0, 0);
+            }
+            if (q < nq) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[e], pa[e], acc, 0, 0, 0);
             }
             *(f32x4*)part_at(blk, col) = acc;
         }
@@ -375,20 +394,24 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const float* aq = s_dctA + lane * c.kk;
             const float* bq = lm_col + ks * c.kk;
-            f32x4 a = *(const f32x4*)aq, bv = *(const f32x4*)bq;
-            for (int q = 0; q < c.kk; q += 4) {
-                const int qn = q + 4 < c.kk ? q + 4 : q;
-                const f32x4 an = *(const f32x4*)(aq + qn);
-                const f32x4 bn = *(const f32x4*)(bq + qn);
+            // (kk is a multiple of 4 and at most 32: every quad's operands are requested at once)
+            const int kk = c.kk;
+#pragma unroll 1
+            for (int q = 0; q < kk; q += 8) {
+                const f32x4 a0 = *(const f32x4*)(aq + q), b0 = *(const f32x4*)(bq + q);
+                const int q1 = q + 4 < kk ? q + 4 : q;
+                const f32x4 a1 = *(const f32x4*)(aq + q1), b1 = *(const f32x4*)(bq + q1);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[e], bv[e], acc, 0, 0, 0);
-                a = an;
-                bv = bn;
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[e], b0[e], acc, 0, 0, 0);
+                if (q + 4 < kk) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[e], b1[e], acc, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = sum_rows(acc[i]);
             // the frame of column `col` belongs to lane group `col` of the FFT stages
-            const int rowi = have ? (int)(row0 + t) : -1;
+            const int rowi = have ? (int)row : -1;
             const int r0 = __builtin_amdgcn_readlane(rowi, 0), r1 = __builtin_amdgcn_readlane(rowi, 16);
             const int r2 = __builtin_amdgcn_readlane(rowi, 32), r3 = __builtin_amdgcn_readlane(rowi, 48);
             const int rc = col == 0 ? r0 : col == 1 ? r1 : col == 2 ? r2 : r3;
@@ -401,11 +424,21 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
         }
         wave_sync();
         }   // any
-        // hand the prefetched chunk over only now: touching xn earlier would wait
-        // for its loads before the transform instead of after it
-        cur = nxt;
-#pragma unroll
-        for (int i = 0; i < 2 * P; ++i) xc[i] = xn[i];
+    };
+    // two steps per trip so that the two sample buffers swap roles without copies
+    float xa[2 * P], xb[2 * P];
+    int s0 = load_start(b_begin), s1 = load_start(b_begin + 1);
+    fetch(s0, b_begin, xa);
+    for (int64_t b = b_begin; b < b_end; b += 2) {
+        fetch(s1, b + 1 < b_end ? b + 1 : b, xb);    // (the last step's repeat is harmless)
+        const int s2 = load_start(b + 2);
+        transform(s0, row_of(b), xa);
+        if (b + 1 >= b_end) break;
+        fetch(s2, b + 2 < b_end ? b + 2 : b + 1, xa);
+        const int s3 = load_start(b + 3);
+        transform(s1, row_of(b + 1), xb);
+        s0 = s2;
+        s1 = s3;
     }
 }
 
@@ -422,8 +455,20 @@ int launch_fast(srx_context* h, const float* audio, const int64_t* so, int64_t U
     if (lds > 160 * 1024) return SRX_EUNSUPPORTED;
     auto kern = cepstra_fast_kernel<P>;
     SRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t chunk = (int64_t)frames_per_block<P>() * d.hop;
-    const int64_t n_chunks = (total + chunk - 1) / chunk;
+    // start sample of every cepstra row (rows as in srx_mfcc_batch: total / hop + 1)
+    const int64_t n_rows = total / d.hop + 1;
+    int32_t* row_start;
+    int rc = srx_ws_ensure(h, WS_MISC, sizeof(int32_t) * (size_t)n_rows, (void**)&row_start);
+    if (rc) return rc;
+    SRX_HIP(hipMemsetAsync(row_start, 0xFF, sizeof(int32_t) * (size_t)n_rows, st));
+    {
+        int64_t g = (U + 3) / 4;
+        const int64_t cap = (int64_t)h->n_cu * 8;
+        if (g > cap) g = cap;
+        hipLaunchKernelGGL(row_start_kernel, dim3((unsigned)g), dim3(256), 0, st, so, U, d.frame_len,
+                           (unsigned)d.hop, d.hop_m, d.hop_s, row_start);
+    }
+    const int64_t n_chunks = (n_rows + frames_per_block<P>() - 1) / frames_per_block<P>();
     // four rounds of the workgroups that fit a CU at once (LDS decides)
     int per_cu = (int)((160 * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
@@ -431,7 +476,8 @@ int launch_fast(srx_context* h, const float* audio, const int64_t* so, int64_t U
     const int64_t want = (int64_t)h->n_cu * per_cu * 4;
     int64_t grid = n_chunks < want ? n_chunks : want;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(16 * frames_per_block<P>()), lds, st, audio, so, U, total, d, cep);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(16 * frames_per_block<P>()), lds, st, audio,
+                       (const int32_t*)row_start, n_rows, total, d, cep);
     SRX_HIP(hipGetLastError());
     return SRX_OK;
 }

@@ -1,0 +1,34 @@
+"""Front-end kernels alone: srx_mfcc_batch through the C ABI with every input (samples,
+offsets) already on the device, timed with events around N back-to-back calls.
+python tools/mfcc_kernel_bench.py [ref]   (ref: the reference's 22.05 kHz / 1024-point shape)"""
+import ctypes as C, os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import speech_recognition_amd as sra
+from speech_recognition_amd._lib import lib, check
+ctx = sra.Context.default(0)
+ref = len(sys.argv) > 1 and sys.argv[1] == "ref"
+n_utt, n_samp = 8192, (66150 if ref else 48000)
+audio = 0.2 * torch.randn((n_utt * n_samp,), device='cuda', dtype=torch.float32)
+so = np.arange(0, (n_utt + 1) * n_samp, n_samp, dtype=np.int64)
+plan = sra.MfccPlan(ctx, 22050, nfft=1024, n_mel=26, delta_order=1, zscore=True) if ref else \
+    sra.MfccPlan(ctx, 16000, nfft=512, n_mel=40, delta_order=2, zscore=True)
+feats, fo = plan.run(audio, so)
+ref_feats = feats.clone()
+so_d, fo_d = ctx.tensor(so), ctx.tensor(fo)
+def call():
+    check(lib.srx_mfcc_batch(ctx.handle, plan._p, C.c_void_p(audio.data_ptr()), 0, C.c_void_p(so_d.data_ptr()),
+                             n_utt, int(so[-1]), C.c_void_p(feats.data_ptr()), C.c_void_p(fo_d.data_ptr()),
+                             ctx.stream_ptr()), "srx_mfcc_batch")
+call(); torch.cuda.synchronize()
+assert torch.equal(feats, ref_feats)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+n = 20
+e0.record()
+for _ in range(n):
+    call()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / n
+L, hop = (551, 220) if ref else (400, 160)
+frames = n_utt * ((n_samp - L) // hop + 1)
+print(f"{'ref' if ref else 'c4'}: {ms:.4f} ms per pass, {frames / ms / 1e6:.3f} Gframes/s, "
+      f"hbm frac {frames * (hop * 4 + plan.n_feat * 4) / ms / 1e6 / 8e3:.4f}, checksum {float(feats.double().sum()):.6f}")
