@@ -27,19 +27,13 @@
 #include "srx_internal.h"
 
 #include <math.h>
-#include <stdlib.h>
-
-#ifndef SRX_FB16
-#define SRX_FB16 16
-#define SRX_WPS16 3
-#endif
 
 namespace {
 
 constexpr int kWave = 64;
 // Frames a workgroup transforms at once (4 per wave).  The 1024-point kernel takes 12:
 // two workgroups of it fit the LDS of a CU, one of 16 frames would be alone.
-template <int P> constexpr int frames_per_block() { return P == 16 ? SRX_FB16 : 12; }
+template <int P> constexpr int frames_per_block() { return P == 16 ? 16 : 12; }
 
 struct FastDev {
     int frame_len, hop, n_used, n_mel, n_ceps, nnz;
@@ -182,7 +176,7 @@ __global__ __launch_bounds__(256) void row_start_kernel(const int64_t* __restric
 }
 
 template <int P>
-__global__ __launch_bounds__(P == 16 ? 16 * SRX_FB16 : 192, P == 16 ? SRX_WPS16 : 2) void cepstra_fast_kernel(
+__global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_fast_kernel(
     const float* __restrict__ audio, const int32_t* __restrict__ row_start, int64_t n_rows, int64_t total,
     FastDev c, float* __restrict__ cep) {
     constexpr int H = 16 * P, N = 2 * H, KB = P / 16;   // KB 16-point FFTs per lane in step 3
@@ -321,6 +315,7 @@ __global__ __launch_bounds__(P == 16 ? 16 * SRX_FB16 : 192, P == 16 ? SRX_WPS16 
         }
         const v2f zh = Y[H / 2];
         wave_sync();                              // Z is in registers: pw may take its place
+
 #pragma unroll
         for (int mm = 0; mm < P / 2; ++mm) {
             const int k = j + 16 * mm;
@@ -348,7 +343,12 @@ __global__ __launch_bounds__(P == 16 ? 16 * SRX_FB16 : 192, P == 16 ? SRX_WPS16 
         wave_sync();
         // ---- 5. mel energies: block `blk` adds its range of bins for 4 filters x 4 frames
         {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // four accumulators, one per bin of a quad: a 4x4x1 product waits for the one before
+            // it only if both add to the same registers, and 4 nq of them in one chain is what
+            // this stage used to spend most of its time waiting for
+            f32x4 ac[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ac[e] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float* wq = s_w4 + lane * 4;
             const float* pq = pw_col + k0;
             // (the next quad's operands are requested before this quad's products; two quads
@@ -360,29 +360,37 @@ __global__ __launch_bounds__(P == 16 ? 16 * SRX_FB16 : 192, P == 16 ? SRX_WPS16 
                 wb = *(const f32x4*)(wq + (q + 1) * 256);
                 pb = *(const f32x4*)(pq + (q + 1) * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[e], pa[e], acc, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) ac[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[e], pa[e], ac[e], 0, 0, 0);
                 const int q2 = q + 2 < nq ? q + 2 : q + 1;
                 wa = *(const f32x4*)(wq + q2 * 256);
                 pa = *(const f32x4*)(pq + q2 * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[e], pb[e], acc, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) ac[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[e], pb[e], ac[e], 0, 0, 0);
             }
             if (q < nq) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[e], pa[e], acc, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) ac[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[e], pa[e], ac[e], 0, 0, 0);
             }
+            const f32x4 acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
             *(f32x4*)part_at(blk, col) = acc;
         }
         wave_sync();
         // blocks of one group of filters add up; exact zeros -> eps; log_mult * log10
+        // log_mult * log10(2) as a float and the part of it the float misses
+        const double scale_d = (double)c.log_mult * 0.30102999566398120;
+        const float log2_scale = (float)scale_d, log2_scale_lo = (float)(scale_d - (double)log2_scale);
         if (blk < c.groups) {
             f32x4 e = {0.f, 0.f, 0.f, 0.f};
             for (int nb = grp_first; nb < grp_first + grp_cnt; ++nb) e += *(const f32x4*)part_at(nb, col);
             f32x4 l;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                // log_mult * log10(v) on the base-2 logarithm instruction; values below 2^-96
+                // (denormals among them, which the instruction does not take) are scaled up first
                 const float v = e[i] == 0.f ? 2.220446049250313e-16f : e[i];
-                l[i] = c.log_mult * __log10f(v);
+                const bool tiny = v < 0x1p-96f;
+                const float l2 = __builtin_amdgcn_logf(tiny ? v * 0x1p32f : v) - (tiny ? 32.f : 0.f);
+                l[i] = fmaf(l2, log2_scale, l2 * log2_scale_lo);
             }
             *(f32x4*)(lm_col + 4 * blk) = l;
         } else if (blk < c.kk) {
@@ -391,10 +399,12 @@ __global__ __launch_bounds__(P == 16 ? 16 * SRX_FB16 : 192, P == 16 ? SRX_WPS16 
         wave_sync();
         // ---- DCT-II rows: 4 cepstra x 4 frames per block, over one slice of the filters
         {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            f32x4 ac[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ac[e] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float* aq = s_dctA + lane * c.kk;
             const float* bq = lm_col + ks * c.kk;
-            // (kk is a multiple of 4 and at most 32: every quad's operands are requested at once)
+            // (kk is a multiple of 4 and at most 32: two quads' operands are requested at once)
             const int kk = c.kk;
 #pragma unroll 1
             for (int q = 0; q < kk; q += 8) {
@@ -402,12 +412,13 @@ __global__ __launch_bounds__(P == 16 ? 16 * SRX_FB16 : 192, P == 16 ? SRX_WPS16 
                 const int q1 = q + 4 < kk ? q + 4 : q;
                 const f32x4 a1 = *(const f32x4*)(aq + q1), b1 = *(const f32x4*)(bq + q1);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[e], b0[e], acc, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) ac[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[e], b0[e], ac[e], 0, 0, 0);
                 if (q + 4 < kk) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[e], b1[e], acc, 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) ac[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[e], b1[e], ac[e], 0, 0, 0);
                 }
             }
+            f32x4 acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = sum_rows(acc[i]);
             // the frame of column `col` belongs to lane group `col` of the FFT stages

@@ -409,14 +409,12 @@ class MfccPlan:
     def out_frames(self, n_samples):
         return int(lib.srx_mfcc_out_frames(C.byref(self.cfg), int(n_samples)))
 
-    def run(self, audio, sample_offsets_host, dtype="float32", out=None):
-        """audio: packed 1-D device tensor (or host array); returns
-        (features [sum T, n_feat] on the device, frame offsets host int64)."""
-        tdt, code, _ = dtype_info(dtype)
-        so = np.asarray(sample_offsets_host, dtype=np.int64)
-        a = self.ctx.tensor(audio, tdt).reshape(-1)
-        if so[-1] != a.numel():
-            raise ValueError(f"sample offsets end at {so[-1]} but audio has {a.numel()} samples")
+    def prepare(self, sample_offsets_host):
+        """Everything a batch needs besides the samples, from its sample offsets: frames per
+        utterance, the offsets on the device, the slices the C calls take.  ``run`` keeps the
+        last one, so repeated batches of the same shape (a stream of equal chunks) upload
+        nothing but samples."""
+        so = np.array(sample_offsets_host, dtype=np.int64)
         lens = np.diff(so)
         L, hop, dn = self.cfg.frame_len, self.cfg.hop, self.cfg.delta_n
         if self.cfg.center:
@@ -428,29 +426,41 @@ class MfccPlan:
         outf = raw if self.cfg.delta_order == 0 else np.maximum(raw - 2 * dn, 0)
         fo = np.zeros(len(lens) + 1, dtype=np.int64)
         np.cumsum(outf, out=fo[1:])
-        if out is None:
-            out = torch.empty((int(fo[-1]), self.n_feat), dtype=tdt, device=self.ctx.device)
-        if fo[-1] == 0:
-            return out, fo
         # The fast kernels address one call's samples with 31 bits: longer buffers go in
         # slices of whole utterances (an utterance that is itself longer runs alone,
         # through the generic kernels).
         limit = (1 << 31) - 512
-        self._keep = [a]
+        slices = []
         u0 = 0
         while u0 < len(lens):
             u1 = int(np.searchsorted(so, so[u0] + limit, side="right")) - 1
             u1 = max(u1, u0 + 1)
-            so_d = self.ctx.tensor(so[u0:u1 + 1] - so[u0])
-            fo_d = self.ctx.tensor(fo[u0:u1 + 1] - fo[u0])
             if fo[u1] > fo[u0]:
-                check(lib.srx_mfcc_batch(self.ctx.handle, self._p, ptr(a[so[u0]:so[u1]]), code,
-                                         ptr(so_d), u1 - u0, int(so[u1] - so[u0]),
-                                         ptr(out[fo[u0]:fo[u1]]), ptr(fo_d), self.ctx.stream_ptr()),
-                      "srx_mfcc_batch")
-            # the offset tensors must outlive the asynchronous kernels
-            self._keep += [so_d, fo_d]
+                slices.append((u0, u1, self.ctx.tensor(so[u0:u1 + 1] - so[u0]),
+                               self.ctx.tensor(fo[u0:u1 + 1] - fo[u0])))
             u0 = u1
+        return {"so": so, "fo": fo, "slices": slices}
+
+    def run(self, audio, sample_offsets_host, dtype="float32", out=None):
+        """audio: packed 1-D device tensor (or host array); returns
+        (features [sum T, n_feat] on the device, frame offsets host int64)."""
+        tdt, code, _ = dtype_info(dtype)
+        so_in = np.asarray(sample_offsets_host, dtype=np.int64)
+        prep = getattr(self, "_prepared", None)
+        if prep is None or prep["so"].shape != so_in.shape or not np.array_equal(prep["so"], so_in):
+            prep = self._prepared = self.prepare(so_in)
+        so, fo = prep["so"], prep["fo"]
+        a = self.ctx.tensor(audio, tdt).reshape(-1)
+        if so[-1] != a.numel():
+            raise ValueError(f"sample offsets end at {so[-1]} but audio has {a.numel()} samples")
+        if out is None:
+            out = torch.empty((int(fo[-1]), self.n_feat), dtype=tdt, device=self.ctx.device)
+        for u0, u1, so_d, fo_d in prep["slices"]:
+            check(lib.srx_mfcc_batch(self.ctx.handle, self._p, ptr(a[so[u0]:so[u1]]), code,
+                                     ptr(so_d), u1 - u0, int(so[u1] - so[u0]),
+                                     ptr(out[fo[u0]:fo[u1]]), ptr(fo_d), self.ctx.stream_ptr()),
+                  "srx_mfcc_batch")
+        self._keep = a          # the samples must outlive the asynchronous kernels
         return out, fo
 
     def close(self):
