@@ -9,8 +9,9 @@
 //   2. multiplies by the twiddles W_H^(j k1);
 //   3. the group transposes through LDS ([k1][j], rows padded to 17) and every
 //      lane does 16-point FFTs over j for its k1 (one for P=16, two for P=32);
-//   4. Z goes back to LDS in natural order; the real-input spectrum is unpacked
-//      from Z[k], Z[H-k], squared and scaled into the power spectrum pw[H+1];
+//   4. the real-input spectrum is unpacked from Z[k], Z[H-k] -- a lane's own lower half and
+//      the upper half of one partner lane, which is all that goes through LDS -- squared and
+//      scaled into the power spectrum pw[H+1];
 //   5. mel energies and DCT rows on the matrix cores, as 4x4x1 instructions: each
 //      is 16 independent 4x4 outer products, one per group of 4 lanes (lane 4b+i
 //      gives row i of A and column i of B; D[i][j] lands in register i of lane
@@ -297,25 +298,37 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
         }
         wave_sync();
 #pragma unroll
-        for (int i = 0; i < KB; ++i) {
-            fft_regs<16>(z2[i]);
-            // Z[k1 + P k2] in natural order over the same LDS region
+        for (int i = 0; i < KB; ++i) fft_regs<16>(z2[i]);
+        // ---- 4. real-input spectrum, power / N.  Bins k and H-k share their inputs.  Lane j now
+        // holds Z[j + 16 m], m < P (m = KB k2 + i).  Its bins k = j + 16 mm, mm < P/2, are its
+        // own lower half; their partners H - k = (16 - j) + 16 (P - 1 - mm) are the UPPER half of
+        // lane (16 - j) mod 16 -- for j = 0 (H - k = 16 (P - mm)) one place further, Z[0] for
+        // mm = 0.  So only half of the spectrum travels: every lane leaves its upper half in LDS
+        // (slot u = m - P/2; lanes P + 4 floats apart: 16-byte stores, 8 lanes in 8 different
+        // groups of 4 banks) and reads its partner's.
+        constexpr int LT = P + 4;
+        float* slots = fr;
 #pragma unroll
-            for (int k2 = 0; k2 < 16; ++k2) Y[j + 16 * i + P * k2] = z2[i][k2];
+        for (int u = 0; u < P / 2; u += 2) {
+            const int m0 = u + P / 2, m1 = m0 + 1;
+            const v2f a = z2[m0 % KB][m0 / KB], b = z2[m1 % KB][m1 / KB];
+            *(f32x4*)(slots + j * LT + 2 * u) = f32x4{a.x, a.y, b.x, b.y};
         }
         wave_sync();
-        // ---- 4. real-input spectrum, power / N.  Bins k and H-k share their inputs.
         const float quarter_inv_n = 0.25f / (float)N;
         v2f zks[P / 2], zcs[P / 2];
+        {
+            const int jp = (16 - j) & 15;
+            const float* sp = slots + jp * LT + (j == 0 ? 2 : 0);
 #pragma unroll
-        for (int mm = 0; mm < P / 2; ++mm) {
-            const int k = j + 16 * mm;            // 0 .. H/2-1 ; partner H-k
-            zks[mm] = Y[k];
-            zcs[mm] = Y[(H - k) & (H - 1)];
+            for (int mm = 0; mm < P / 2; ++mm) {
+                zks[mm] = z2[mm % KB][mm / KB];
+                zcs[mm] = *(const v2f*)(sp + 2 * (P / 2 - 1 - mm));
+            }
+            if (j == 0) zcs[0] = z2[0][0];
         }
-        const v2f zh = Y[H / 2];
-        wave_sync();                              // Z is in registers: pw may take its place
-
+        const v2f zh = z2[0][8];                  // Z[H/2], lane 0's (the only lane that uses it)
+        wave_sync();                              // the slots are in registers: pw may take their place
 #pragma unroll
         for (int mm = 0; mm < P / 2; ++mm) {
             const int k = j + 16 * mm;
