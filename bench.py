@@ -146,6 +146,8 @@ def main():
     ap.add_argument("--train-utts", type=int, default=0,
                     help="utterances per GPU for the Baum-Welch extra (default: the config's "
                          "1,048,576 utterances in total, split over the GPUs)")
+    ap.add_argument("--prewarm", type=int, default=150,
+                    help="untimed passes before the warm-up steps that bring the clock to its steady state")
     ap.add_argument("--no-train", action="store_true", help="skip the Baum-Welch measurement")
     ap.add_argument("--all-extra", action="store_true",
                     help="run the secondary extra lines on more than one GPU too")
@@ -205,6 +207,11 @@ def main():
     bank = sra.HMMBank(ctx, sp, A, mu, cv)
     scores = torch.empty((U, N_MODELS), dtype=torch.float64, device=dev)
 
+    # The chip raises its clock over the first tens of milliseconds of load (a scoring pass
+    # takes 0.67 ms right after start-up and 0.54 ms from about 40 ms on): the steady state is
+    # what is measured, so load comes first, then the W warm-up steps, then the K timed ones.
+    for _ in range(args.prewarm):
+        bank.score(data, out=scores)
     for _ in range(args.warmup):
         bank.score(data, out=scores)
     barrier()
@@ -254,6 +261,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
         "checksum": checksum,
+        "prewarm_passes": args.prewarm,
     }
 
     # what the arithmetic named in "dtype" costs: the same scores in float64 (the validation
@@ -452,7 +460,8 @@ def main():
         sp2, A2, mu2, cv2 = synth_models(np.random.default_rng(8), N_MODELS, 16, N_FEAT)
         bank2 = sra.HMMBank(ctx, sp2, A2, mu2, cv2)
         tr = sra.parallel.BaumWelchTrainer(bank2, dt_, np.arange(Ut) % N_MODELS)
-        tr.step()
+        for _ in range(3):
+            tr.step()
         barrier()
         t0 = time.perf_counter()
         iters = 5

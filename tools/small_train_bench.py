@@ -28,4 +28,32 @@ for dtype in ("float32", "float64"):
         lp = tr.step()
         float(lp.sum().item())          # the convergence check of fit()
     dts = (time.perf_counter() - t0) / n
-    print(f"{dtype}: {dt*1e6:.0f} us per EM iteration ({dts*1e6:.0f} us with a host read of the log-probability each)")
+    # convergence checking the way MyGaussianHMM.fit does it: the log-probability of iteration k
+    # goes to pinned host memory asynchronously and is looked at while iteration k + 1 runs
+    logp = torch.empty((n,), dtype=torch.float64).pin_memory()
+    ev = [torch.cuda.Event() for _ in range(2)]
+    hist = []
+    t0 = time.perf_counter()
+    for k in range(n):
+        lp = tr.step()
+        logp[k:k + 1].copy_(lp.sum().reshape(1), non_blocking=True)
+        ev[k % 2].record()
+        if k >= 1:
+            ev[(k - 1) % 2].synchronize()
+            hist.append(float(logp[k - 1]))
+    torch.cuda.synchronize()
+    dtl = (time.perf_counter() - t0) / n
+    print(f"{dtype}: {dt*1e6:.0f} us per EM iteration; {dts*1e6:.0f} us with a blocking host read of the "
+          f"log-probability each; {dtl*1e6:.0f} us with the check one iteration behind")
+# the class itself (one model, float64 and float32), convergence checking on, no early stop
+Xs = X[:int(lengths[:25].sum())]
+for dtype in ("float32", "float64"):
+    m = sra.MyGaussianHMM(n_components=S, n_iter=60, tol=-1e300, verbose=False, dtype=dtype, random_state=0)
+    np.random.seed(0)
+    m.init(Xs, lengths[:25])
+    m.fit_from_current(Xs, lengths[:25])
+    t0 = time.perf_counter()
+    m.fit_from_current(Xs, lengths[:25])
+    dt = (time.perf_counter() - t0) / m.monitor_.iter
+    print(f"MyGaussianHMM.fit_from_current {dtype}: {dt*1e6:.0f} us per EM iteration over {m.monitor_.iter} iterations "
+          f"(25 utterances, convergence checked every iteration)")
