@@ -631,8 +631,8 @@ int launch(srx_context* h, const float* X, const int64_t* off, int64_t U, int64_
 // -- ascending utterance index inside a model -- is the same on every run and keeps
 // a model's utterances in memory order.
 //   order_hist_kernel     per workgroup of 256 utterances: counts per model
-//   order_offsets_kernel  per model: exclusive prefix of those counts over the workgroups
-//                         (in place) and the model's total
+//   order_offsets_kernel  per model (one block each): exclusive prefix of those counts over the
+//                         workgroups (in place) and the model's total
 //   order_bases_kernel    exclusive prefix of the padded totals over the models
 //   order_scatter_kernel  position = model base + workgroup prefix + rank among the
 //                         workgroup's lower-numbered utterances of that model
@@ -648,17 +648,30 @@ __global__ __launch_bounds__(256) void order_hist_kernel(const int32_t* __restri
     __syncthreads();
     for (int m = threadIdx.x; m < M; m += blockDim.x) wg_count[(size_t)blockIdx.x * M + m] = hist[m];
 }
-__global__ void order_offsets_kernel(unsigned* __restrict__ wg_count, int64_t n_wg, int M,
-                                     unsigned long long* __restrict__ total) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    unsigned long long run = 0;
-    for (int64_t w = 0; w < n_wg; ++w) {
+__global__ __launch_bounds__(256) void order_offsets_kernel(unsigned* __restrict__ wg_count, int64_t n_wg,
+                                                            int M, unsigned long long* __restrict__ total) {
+    // one block per model: each thread owns a run of workgroups, a block scan joins the runs
+    __shared__ unsigned long long part[256];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const int64_t per = (n_wg + 255) / 256;
+    const int64_t w0 = tid * per, w1 = w0 + per < n_wg ? w0 + per : n_wg;
+    unsigned long long sum = 0;
+    for (int64_t w = w0; w < w1; ++w) sum += wg_count[(size_t)w * M + m];
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const unsigned long long v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    unsigned long long run = part[tid] - sum;
+    for (int64_t w = w0; w < w1; ++w) {
         const unsigned c = wg_count[(size_t)w * M + m];
         wg_count[(size_t)w * M + m] = (unsigned)run;
         run += c;
     }
-    total[m] = run;
+    if (tid == 255) total[m] = part[255];
 }
 __global__ void order_bases_kernel(unsigned long long* total, int M) {
     unsigned long long run = 0;
@@ -704,7 +717,7 @@ static int build_model_order(srx_context* h, const int32_t* utt_model, int64_t U
     unsigned* wg_count = (unsigned*)(ord + E);
     SRX_HIP(hipMemsetAsync(ord, 0xFF, sizeof(int64_t) * (size_t)E, st));
     hipLaunchKernelGGL(order_hist_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, utt_model, U, M, wg_count);
-    hipLaunchKernelGGL(order_offsets_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, wg_count,
+    hipLaunchKernelGGL(order_offsets_kernel, dim3((unsigned)M), dim3(256), 0, st, wg_count,
                        n_wg, M, total);
     hipLaunchKernelGGL(order_bases_kernel, dim3(1), dim3(1), 0, st, total, M);
     hipLaunchKernelGGL(order_scatter_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, utt_model, U, M,

@@ -625,6 +625,81 @@ int srx_mfma_emission_utt_f32(srx_context* h, const void* X, const int64_t* off,
     return SRX_EUNSUPPORTED;
 }
 
+// Batches of 16 consecutive utterances whose frames span 4 GiB or more are out of the reach
+// of the split kernel's one descriptor per batch (32-bit offsets); it leaves them alone and
+// this kernel scores exactly those: one wave per (utterance, model) pair, 64-bit addresses,
+// float64 arithmetic, lanes = 4 feature groups x 16 states.  Correct for any length; a
+// wave walks its utterance frame by frame, so it is no faster than the recursion is long.
+namespace {
+__global__ __launch_bounds__(64) void score_far_kernel(const float* __restrict__ X,
+                                                       const int64_t* __restrict__ off, int64_t U,
+                                                       srx_models_t md, double* __restrict__ out) {
+    const int M = md.n_models, S = md.n_states, D = md.n_features;
+    const int64_t u_first = (int64_t)blockIdx.x * 16;
+    const int64_t u_last = u_first + 15 < U - 1 ? u_first + 15 : U - 1;
+    if ((off[u_last + 1] - off[u_first]) * D * 4 < 0xFFFFFF00ll) return;
+    const int64_t u = u_first + blockIdx.y;
+    if (u >= U) return;
+    const int lane = threadIdx.x, g = lane >> 4, s = lane & 15;
+    const int64_t f0 = off[u], T = off[u + 1] - f0;
+    for (int m = blockIdx.z; m < M; m += gridDim.z) {
+        double mu[12], hv[12], Acol[16], cpart = 0.0;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const int d = g + 4 * j;
+            mu[j] = hv[j] = 0.0;
+            if (s < S && d < D) {
+                const size_t k = ((size_t)m * S + s) * D + d;
+                const double var = fmax(md.covars[k], 2.2250738585072014e-308);
+                mu[j] = md.means[k];
+                hv[j] = 0.5 / var;
+                cpart += log(var);
+            }
+        }
+        cpart += __shfl_xor(cpart, 16, 64);
+        cpart += __shfl_xor(cpart, 32, 64);
+        const double cst = -0.5 * (cpart + D * 1.8378770664093453);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            Acol[j] = (j < S && s < S) ? md.transmat[((size_t)m * S + j) * S + s] : 0.0;
+        const double pi = s < S ? md.startprob[(size_t)m * S + s] : 0.0;
+        double alpha = 0.0, lp = 0.0;
+        for (int64_t t = 0; t < T; ++t) {
+            const float* x = X + (f0 + t) * D;
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const int d = g + 4 * j;
+                const double dx = (d < D ? (double)x[d] : 0.0) - mu[j];
+                acc += dx * dx * hv[j];
+            }
+            acc += __shfl_xor(acc, 16, 64);
+            acc += __shfl_xor(acc, 32, 64);
+            const double ll = s < S ? cst - acc : -INFINITY;
+            double mx = ll;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+            const double b = exp(ll - mx);
+            double a;
+            if (t == 0) {
+                a = pi * b;
+            } else {
+                a = 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) a += __shfl(alpha, (lane & 48) | j, 64) * Acol[j];
+                a *= b;
+            }
+            double c = a;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) c += __shfl_xor(c, o, 64);
+            lp += log(c) + mx;
+            alpha = a / c;
+        }
+        if (lane == 0) out[u * M + m] = lp;
+    }
+}
+}  // namespace
+
 int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
                    const srx_models_t* md, double* out, hipStream_t st) {
     return srx_mfma_score_tables(h, X, off, U, n_frames, md, out, nullptr, 0, st);
@@ -672,10 +747,20 @@ int srx_mfma_score_tables(srx_context* h, const void* X, const int64_t* off, int
         hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, SP, NTP, RQ, H, base,
                            cst, A, pi);
         const float* Xf = (const float*)X;
+        int rc;
         if (SP == 16)
-            return srx_split_score_sp16(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st);
-        return SP == 8 ? srx_split_score_sp8(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st)
-                       : srx_split_score_sp4(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st);
+            rc = srx_split_score_sp16(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st);
+        else
+            rc = SP == 8 ? srx_split_score_sp8(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st)
+                         : srx_split_score_sp4(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st);
+        if (rc) return rc;
+        // only a buffer of 4 GiB or more can hold a batch the split kernel has skipped
+        if (n_frames * (int64_t)D * 4 >= 0xFFFFFF00ll) {
+            hipLaunchKernelGGL(score_far_kernel, dim3((unsigned)((U + 15) / 16), 16, (unsigned)(M < 4 ? M : 4)),
+                               dim3(64), 0, st, Xf, off, U, *md, out);
+            SRX_HIP(hipGetLastError());
+        }
+        return SRX_OK;
     }
     if (NT > 3 || tables) return SRX_EUNSUPPORTED;
     const int KQ = 4 * R;

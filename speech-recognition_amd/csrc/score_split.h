@@ -167,12 +167,14 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
     const int64_t span = (off[u_last + 1] - fbase) * D * 4;           // bytes, uniform
     const int64_t rest = (n_frames - fbase) * (int64_t)D * 4;
     const unsigned nrec = (unsigned)(rest < 0xFFFFFF00ll ? rest : 0xFFFFFF00ll);
-    const bool span_ok = span < 0xFFFFFF00ll;
+    // One descriptor reaches 4 GiB.  A batch whose frames span more is left to
+    // score_far_kernel (launched after this one whenever X is that large).
+    if (span >= 0xFFFFFF00ll) return;
     const unsigned base_lo = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)(X + fbase * D)));
     const unsigned base_hi = __builtin_amdgcn_readfirstlane((unsigned)(((uintptr_t)(X + fbase * D)) >> 32));
     const float* xb = (const float*)(((uintptr_t)base_hi << 32) | base_lo);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)xb, 0, __builtin_amdgcn_readfirstlane(span_ok ? nrec : 0u), 0x00020000);
+        (void*)xb, 0, __builtin_amdgcn_readfirstlane(nrec), 0x00020000);
     const unsigned row_off = (unsigned)((f0 - fbase) * D * 4) + 16u * g;   // this lane, frame 0, q = 0
     const unsigned row_bytes = (unsigned)D * 4u;
 
@@ -437,9 +439,7 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const bool writer = SP == 4 ? true : (SP == 8 ? (g & 1) == 0 : g == 0);
-            // a batch spanning 4 GiB or more cannot be addressed: report NaN, not garbage
-            if (writer && model[nt] < M)
-                out[u * M + model[nt]] = span_ok ? lp[nt] * kLn2 : __builtin_nan("");
+            if (writer && model[nt] < M) out[u * M + model[nt]] = lp[nt] * kLn2;
         }
     }
 }

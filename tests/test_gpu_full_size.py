@@ -295,6 +295,41 @@ def test_addressing_beyond_4gib(sra, ctx):
     assert torch.equal(ll, ll_all_tail)
 
 
+def test_score_batch_spanning_4gib(sra, ctx):
+    """A batch of 16 consecutive utterances whose frames span more than 4 GiB (13 of
+    1.75 M frames x 48 floats and 3 short ones) is out of the matrix-core kernel's reach and
+    takes the far-batch kernel: its short utterances agree with the oracle, two long ones
+    with the same data scored on its own (a batch of one, matrix-core kernel), and the
+    ordinary batch that follows in the same call with its own call."""
+    import torch
+    D, M, S, L = 48, 2, 5, 1_750_000
+    lengths = np.array([200, L, L, L, L, 150, L, L, L, L, L, 1, L, L, L, L] + [300, 250, 1, 40, 77], dtype=np.int64)
+    assert int(lengths[:16].sum()) * D * 4 >= 1 << 32
+    n = int(lengths.sum())
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    X = torch.empty((n, D), device="cuda", dtype=torch.float32)
+    for i in range(0, n, 1 << 22):
+        X[i:i + (1 << 22)].normal_(generator=g)
+    rng = np.random.default_rng(31)
+    prms = _models(rng, M, S, D)
+    bank = _bank(sra, ctx, prms)
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    sc = bank.score(sra.Ragged(ctx, X, lengths, dtype="float32")).cpu().numpy()
+    assert sc.shape == (len(lengths), M) and np.isfinite(sc).all()
+    for u in (0, 5, 11):                                   # short utterances of the far batch: oracle
+        x = X[off[u]:off[u + 1]].cpu().numpy().astype(np.float64)
+        for m in range(M):
+            want = ho.score(prms[m], x)
+            assert abs(sc[u, m] - want) <= 1e-9 * abs(want) + 1e-9
+    for u in (1, 15):                                      # long ones: the same frames in a batch of one
+        alone = bank.score(sra.Ragged(ctx, X[off[u]:off[u + 1]], [int(lengths[u])], dtype="float32")).cpu().numpy()
+        assert np.abs(sc[u] - alone[0]).max() <= 1e-5 * np.abs(alone).max()
+    tail = bank.score(sra.Ragged(ctx, X[off[16]:], lengths[16:], dtype="float32")).cpu().numpy()
+    assert np.array_equal(sc[16:], tail)
+    del X
+
+
 def test_training_config_full_size(sra, ctx):
     """The training configuration at its full size on one GPU: 1,048,576 utterances x 200
     frames x 39 dims (31 GB of features), 6 models x 16 states.

@@ -1,19 +1,31 @@
+"""Time of the fused E-step alone (float32, 131072 utterances x 200 frames x 39 features, 6 models
+x 16 states) after the clock has ramped up: best and median of 5 groups of 4 calls."""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import speech_recognition_amd as sra
 ctx = sra.Context.default(0)
-U, T, D, M, S = 131072, 200, 39, 6, 16
+U, T, D, M, S = int(os.environ.get("ES_U", 131072)), 200, 39, 6, 16
 X = torch.randn((U * T, D), device='cuda', dtype=torch.float32)
 off = torch.arange(0, (U + 1) * T, T, device='cuda', dtype=torch.int64)
 data = sra.Ragged(ctx, X, offsets=off, dtype="float32")
 rng = np.random.default_rng(8)
 bank = sra.HMMBank(ctx, rng.dirichlet(np.ones(S), size=M), rng.dirichlet(np.ones(S), size=(M, S)),
                    rng.standard_normal((M, S, D)), rng.uniform(0.5, 1.5, (M, S, D)))
-tr = sra.parallel.BaumWelchTrainer(bank, data, np.arange(U) % M)
-tr.step(); torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(3):
-    lp = tr.step()
+# ES_UM=block: each model's utterances contiguous in memory; default: round robin over the models
+um_host = np.arange(U) * M // U if os.environ.get("ES_UM") == "block" else np.arange(U) % M
+um = torch.as_tensor(um_host, dtype=torch.int32, device='cuda')
+out = None
+for _ in range(6):
+    out = bank.estep(data, um, out=out)
 torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / 3
-print("ms/iter", dt * 1e3, "frames/s", U * T / dt, "logprob0", float(lp[0]))
+ts = []
+for _ in range(5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(4):
+        out = bank.estep(data, um, out=out)
+    e1.record(); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1) / 4)
+st = out.cpu().numpy()
+print(f"estep ms/call best {min(ts):.3f} median {sorted(ts)[2]:.3f}  frames/s {U*T/min(ts)*1e3:.3e}  "
+      f"checksum {float(np.abs(st).sum()):.10e} finite {bool(np.isfinite(st).all())}")

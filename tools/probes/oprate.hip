@@ -37,6 +37,16 @@
 #define OP_CVTF16(r) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %0" : "+v"(r) : "v"(x));
 #define OP_PKADDF16(r) asm volatile("v_pk_add_f16 %0, %1, %0" : "+v"(r) : "v"(x));
 #define OP_PKMAXF16(r) asm volatile("v_pk_max_f16 %0, %1, %0" : "+v"(r) : "v"(x));
+#define OP_CNDE64(r) asm volatile("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(r) : "v"(x), "s"(sm64));
+#define OP_CNDE64Z(r) asm volatile("v_cndmask_b32_e64 %0, 0, %0, %1" : "+v"(r) : "s"(sm64));
+#define OP_MULLO(r) asm volatile("v_mul_lo_u32 %0, %1, %0" : "+v"(r) : "v"(x));
+#define OP_BCNT(r) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(r) : "v"(x));
+#define OP_LSHLOR(r) asm volatile("v_lshl_or_b32 %0, %1, 6, %0" : "+v"(r) : "v"(x));
+#define OP_MINI(r) asm volatile("v_min_i32 %0, %1, %0" : "+v"(r) : "v"(x));
+#define OP_CVTF64(r) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d##r) : "v"(r));
+#define OP_ADDF64(r) asm volatile("v_add_f64 %0, %1, %0" : "+v"(d##r) : "v"(dx));
+#define OP_SWAP32(r) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(r), "+v"(x));
+#define OP_RCP(r) asm volatile("v_rcp_f32 %0, %0" : "+v"(r));
 #define OP_DPP(r) asm volatile("v_add_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(x));
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -44,12 +54,14 @@ typedef float f2 __attribute__((ext_vector_type(2)));
     __global__ __launch_bounds__(256) void k_##NAME(float* out, int iters) {          \
         float r0 = threadIdx.x, r1 = 1, r2 = 2, r3 = 3, r4 = 4, r5 = 5, x = 0.999f, y = 1e-3f; \
         unsigned sm = 0xffff0000u; asm volatile("" : "+s"(sm));                       \
+        unsigned long long sm64 = 0x0f0f0f0f0f0f0f0full; asm volatile("" : "+s"(sm64));   \
+        double dr0 = r0, dr1 = 1, dr2 = 2, dr3 = 3, dr4 = 4, dr5 = 5, dx = 1.5;      \
         f2 pr0 = {r0, 1}, pr1 = pr0, pr2 = pr0, pr3 = pr0, pr4 = pr0, pr5 = pr0, px = {x, y};  \
         for (int it = 0; it < iters; ++it) { REP48(OP) }                              \
-        out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + x + pr0[0] + pr1[1] + pr2[0] + pr3[1] + pr4[0] + pr5[1]; \
+        out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + x + pr0[0] + pr1[1] + pr2[0] + pr3[1] + pr4[0] + pr5[1] + (float)(dr0 + dr1 + dr2 + dr3 + dr4 + dr5); \
     }
 #define LIST(X) X(FMA) X(FMAC) X(ADD) X(SUB) X(MUL) X(MULLEG) X(MAX) X(MAX3) X(AND) X(ANDLIT) X(ANDSGPR) X(SUBSGPR) X(SUBE64) X(ADDLIT) X(ADDINL) X(FMA3) X(PERMSGPR) X(LSHL) X(BFI) X(ADDU) X(PERM) X(CVTPK) X(CVTF16) \
-    X(DOT2C) X(MOV) X(CNDMASK) X(EXP) X(LOG) X(PKMUL) X(PKFMA) X(PKADD) X(PKADDF16) X(PKMAXF16) X(SWAP) X(DPP)
+    X(DOT2C) X(MOV) X(CNDMASK) X(EXP) X(LOG) X(PKMUL) X(PKFMA) X(PKADD) X(PKADDF16) X(PKMAXF16) X(SWAP) X(DPP) X(CNDE64) X(CNDE64Z) X(MULLO) X(BCNT) X(LSHLOR) X(MINI) X(CVTF64) X(ADDF64) X(SWAP32) X(RCP)
 #define DEF(N) KERNEL(N, OP_##N)
 LIST(DEF)
 
