@@ -25,6 +25,8 @@ Differences from the reference, on purpose:
 import sys
 from collections import deque
 
+import warnings
+
 import numpy as np
 
 from . import _lib
@@ -156,6 +158,14 @@ class MyGaussianHMM:
 
     def _bank(self):
         ctx = self._ctx()
+        if self.dtype == "float32":
+            # the float32 kernels evaluate the Gaussian exponent in expanded form (see
+            # HMMBank.conditioning): fine for normalised features, not for raw ones
+            cond = float(np.max(np.square(self.means_) / self._covars_))
+            if cond > 1e4:
+                warnings.warn(f"means are up to {cond ** 0.5:.0f} standard deviations from zero: float32 scoring "
+                              "loses accuracy on such features, use dtype='float64' or normalise them",
+                              RuntimeWarning, stacklevel=3)
         return HMMBank(ctx, self.startprob_, self.transmat_, self.means_, self._covars_)
 
     def _data(self, X, lengths):

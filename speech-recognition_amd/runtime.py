@@ -184,6 +184,16 @@ class HMMBank:
                    np.stack([m.means_ for m in models]),
                    np.stack([m._covars_ for m in models]))
 
+    def conditioning(self):
+        """max of mean^2 / variance over the bank (synchronises).  The matrix-core paths
+        evaluate the Gaussian exponent in expanded form, cst + x mean/var - x^2/(2 var), whose
+        rounding error per frame is eps * sum_d (|x mean|/var + x^2/(2 var)) with eps = 2^-16
+        for float32 scoring (split-bf16 operands), 2^-23 for the exact-f32 mode and the fused
+        E-step, 2^-52 in float64: harmless for z-scored features such as the front-end's
+        (this number is then of order 10), not for raw features far from zero in units of
+        their spread (1e6 and more); use float64 for those, or shift the features."""
+        return float((self.means * self.means / self.covars).max().item())
+
     def _check(self, data):
         if data.D != self.D:
             raise ValueError(

@@ -703,6 +703,62 @@ def test_float64_matrix_core_scoring_equals_generic(sra, ctx, M, S, D):
             np.testing.assert_allclose(fast[k, mi], ho.score(prms[mi], x, loops=False), rtol=1e-11)
 
 
+def test_offset_features_stay_within_the_expanded_form_bound(sra, ctx):
+    """Features that are not z-scored (mean 3e2, variances 1e-2 .. 1e2): the matrix-core
+    paths evaluate cst + x mu/var - x^2/(2 var), whose terms cancel here.  Scores stay within
+    eps * sum over frames of max_s sum_d (|x mu|/var + x^2/(2 var)) of the oracle's, eps the
+    unit of the path's arithmetic: float64 keeps 1e-9 relative even here, float32 does not
+    (the front-end's z-scored features are what the float32 paths are for)."""
+    rng = np.random.default_rng(77)
+    M, S, D = 3, 5, 13
+    prms = [ho.random_params(rng, S, D) for _ in range(M)]
+    var0 = 10.0 ** rng.uniform(-2, 2, size=(S, D))
+    mu0 = 300.0 + 2.0 * np.sqrt(var0) * rng.standard_normal((S, D))
+    for p in prms:                                            # word models a fraction of a sigma apart
+        p.covars[:] = var0 * rng.uniform(0.8, 1.25, size=(S, D))
+        p.means[:] = mu0 + 0.3 * np.sqrt(var0) * rng.standard_normal((S, D))
+    lengths = np.array([40, 1, 120, 64], dtype=np.int64)
+    states = rng.integers(0, S, size=int(lengths.sum()))
+    X = prms[0].means[states] + np.sqrt(prms[0].covars[states]) * rng.standard_normal((len(states), D))
+    X = X.astype(np.float32).astype(np.float64)              # the same numbers in both dtypes
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    want = np.array([[float(np.sum(ho.score(p, X[off[u]:off[u + 1]], loops=False))) for p in prms]
+                     for u in range(len(lengths))])
+    mag = np.zeros_like(want)
+    for mi, p in enumerate(prms):
+        terms = (np.abs(X[:, None, :] * p.means[None]) / p.covars[None] + X[:, None, :] ** 2 / (2 * p.covars[None])).sum(-1)
+        for u in range(len(lengths)):
+            mag[u, mi] = terms[off[u]:off[u + 1]].max(axis=1).sum()
+    bank = _bank(sra, ctx, prms)
+    assert bank.conditioning() > 1e6
+    got64 = bank.score(sra.Ragged(ctx, X, lengths, dtype="float64")).cpu().numpy()
+    e64 = np.abs(got64 - want)
+    assert (e64 <= 16 * 2.0 ** -52 * mag).all() and (e64 <= 1e-9 * np.abs(want)).all()
+    gen64 = bank.score(sra.Ragged(ctx, X, lengths, dtype="float64"), generic=True).cpu().numpy()
+    np.testing.assert_allclose(gen64, want, rtol=1e-12)
+    got32 = bank.score(sra.Ragged(ctx, X, lengths, dtype="float32")).cpu().numpy()
+    e32 = np.abs(got32 - want)
+    print("offset features: float64 error / bound", float((e64 / (2.0 ** -52 * mag)).max()),
+          "float32 (split) error / bound", float((e32 / (2.0 ** -16 * mag)).max()),
+          "relative", float((e32 / np.abs(want)).max()))
+    assert (e32 <= 4 * 2.0 ** -16 * mag).all()
+    ctx.set_exact_f32(True)
+    try:
+        gotx = bank.score(sra.Ragged(ctx, X, lengths, dtype="float32")).cpu().numpy()
+    finally:
+        ctx.set_exact_f32(False)
+    # the model class says so when asked for float32 on such a model, and float64 agrees
+    m = sra.MyGaussianHMM(n_components=S, verbose=False, dtype="float32")
+    m.startprob_, m.transmat_, m.means_, m._covars_ = prms[0].pi, prms[0].A, prms[0].means, prms[0].covars
+    with pytest.warns(RuntimeWarning, match="standard deviations from zero"):
+        m.score(X, lengths)
+    m.dtype = "float64"
+    assert abs(m.score(X, lengths) - want[:, 0].sum()) <= 1e-9 * abs(want[:, 0].sum())
+    ex = np.abs(gotx - want)
+    print("exact float32 error / bound", float((ex / (2.0 ** -23 * mag)).max()), "relative", float((ex / np.abs(want)).max()))
+    assert (ex <= 16 * 2.0 ** -23 * mag).all()
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_estep_without_utterances_or_frames(sra, ctx, dtype):
     """No utterance at all, and utterances that are all empty: the statistics are zeros (the

@@ -14,6 +14,8 @@ bank = sra.HMMBank(ctx, rng.dirichlet(np.ones(S), size=M), rng.dirichlet(np.ones
                    rng.standard_normal((M, S, D)), rng.uniform(0.5, 1.5, (M, S, D)))
 ll = bank.emission_loglik(data)
 torch.cuda.synchronize()
+from _warm import warm
+warm(lambda: bank.emission_loglik(data))
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 n = 10
 ev0.record()

@@ -13,6 +13,8 @@ audio.view(R, n)[:, n // 3:2 * n // 3] *= 200.0
 so = np.arange(0, (R + 1) * n, n, dtype=np.int64)
 res = sra.endpoint.detect_batch(audio, so, fs, ctx=ctx)
 torch.cuda.synchronize()
+from _warm import warm
+warm(lambda: sra.endpoint.detect_batch(audio, so, fs, ctx=ctx))
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 k = 5
 ev0.record()

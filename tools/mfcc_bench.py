@@ -23,6 +23,8 @@ else:
     plan = sra.MfccPlan(ctx, 16000, nfft=512, n_mel=40, delta_order=order, zscore=zs)
 feats, fo = plan.run(audio, so)
 torch.cuda.synchronize()
+from _warm import warm
+warm(lambda: plan.run(audio, so, out=feats))
 t0 = time.perf_counter()
 for _ in range(5):
     plan.run(audio, so, out=feats)

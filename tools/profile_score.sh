@@ -10,8 +10,10 @@ OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"
 cd /tmp
 export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --steps 10 --warmup 2 --no-extra --no-cpu"
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_kt" -o score -- $CMD > "$OUT/prof_kt.log" 2>&1
+# kernel times: the default bench command (without its CPU leg); counters: the scoring part alone
+CMD="python3 $ROOT/bench.py --no-extra --no-train --no-cpu"
+rm -rf "$OUT/prof_kt" "$OUT/prof_fetch" "$OUT/prof_write"
+timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_kt" -o score -- python3 $ROOT/bench.py --no-cpu > "$OUT/prof_kt.log" 2>&1
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/prof_fetch" -o score -- $CMD > "$OUT/prof_fetch.log" 2>&1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/prof_write" -o score -- $CMD > "$OUT/prof_write.log" 2>&1
 find "$OUT" -name "*.csv" | head -20

@@ -17,6 +17,8 @@ bank = sra.HMMBank(ctx, rng.dirichlet(np.ones(S), size=M), rng.dirichlet(np.ones
 um = ctx.tensor((np.arange(U) % M).astype(np.int32))
 lp, path = bank.viterbi(data, um)
 torch.cuda.synchronize()
+from _warm import warm
+warm(lambda: bank.viterbi(data, um))
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 n = 5
 ev0.record()
