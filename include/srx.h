@@ -114,8 +114,14 @@ int srx_destroy(srx_handle_t h);
 /* Context options.  SRX_OPT_EXACT_F32 = 1 keeps the SRX_F32 scoring path on
  * exact-f32 matrix instructions; the default (0) evaluates the emission
  * contraction with split-bf16 operands (three partial products, error ~1e-6
- * relative on a log-likelihood), which is several times faster. */
-enum srx_option { SRX_OPT_EXACT_F32 = 1 };
+ * relative on a log-likelihood), which is several times faster.
+ * SRX_OPT_ESTEP_PATH chooses the kernels of the SRX_F32 E-step: SRX_ESTEP_AUTO (0,
+ * default) takes one lane per utterance for small jobs (at most 8 states and, by the
+ * number of states, 3072 to 8192 utterances) and the fused matrix-core kernel otherwise; SRX_ESTEP_FUSED (1) and
+ * SRX_ESTEP_LANE (2) ask for one of the two wherever its limits allow (tests, timing).
+ * The results agree to float32 rounding. */
+enum srx_option { SRX_OPT_EXACT_F32 = 1, SRX_OPT_ESTEP_PATH = 2 };
+enum srx_estep_path { SRX_ESTEP_AUTO = 0, SRX_ESTEP_FUSED = 1, SRX_ESTEP_LANE = 2 };
 int srx_set_option(srx_handle_t h, int option, int value);
 /* Bytes of scratch currently held by the context (diagnostics). */
 int64_t srx_workspace_bytes(srx_handle_t h);

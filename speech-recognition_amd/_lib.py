@@ -17,6 +17,8 @@ LIB_PATH = os.environ.get("SRX_LIB") or os.path.join(_HERE, "libsrx.so")
 SRX_F32, SRX_F64 = 0, 1
 SRX_MSTEP_FULL, SRX_MSTEP_TRANSITIONS_ONLY = 0, 1
 SRX_OPT_EXACT_F32 = 1
+SRX_OPT_ESTEP_PATH = 2
+SRX_ESTEP_AUTO, SRX_ESTEP_FUSED, SRX_ESTEP_LANE = 0, 1, 2
 SRX_EINVAL, SRX_EHIP, SRX_ENOMEM, SRX_EUNSUPPORTED = -1, -2, -3, -4
 
 

@@ -141,6 +141,10 @@ int srx_set_option(srx_handle_t h, int option, int value) {
     SRX_REQUIRE(h != nullptr, "srx_set_option: NULL context");
     switch (option) {
         case SRX_OPT_EXACT_F32: h->exact_f32 = value != 0; return SRX_OK;
+        case SRX_OPT_ESTEP_PATH:
+            SRX_REQUIRE(value >= SRX_ESTEP_AUTO && value <= SRX_ESTEP_LANE, "srx_set_option: unknown E-step path %d", value);
+            h->estep_path = value;
+            return SRX_OK;
         default: srx_set_error("srx_set_option: unknown option %d", option); return SRX_EINVAL;
     }
 }
@@ -377,6 +381,12 @@ static int estep_common(srx_handle_t h, const void* X, int dtype, const int64_t*
     SRX_REQUIRE(out_stats != nullptr, "%s: NULL out_stats", who);
     SRX_HIP(hipSetDevice(h->device));
     if (allow_fused && dtype == SRX_F32) {
+        // small jobs first: one lane per utterance beats a matrix-core wave they cannot fill
+        if (h->estep_path != SRX_ESTEP_FUSED) {
+            rc = srx_lane_estep(h, X, utt_offsets, n_utts, n_frames, utt_model, utt_order, models, out_stats,
+                                (hipStream_t)stream);
+            if (rc != SRX_EUNSUPPORTED) return rc;
+        }
         rc = srx_fused_estep(h, X, utt_offsets, n_utts, n_frames, utt_model, utt_order, models,
                              out_stats, (hipStream_t)stream);
         if (rc != SRX_EUNSUPPORTED) return rc;

@@ -423,6 +423,112 @@ __global__ void obs_stats_kernel(const T* __restrict__ X, const T* __restrict__ 
 #undef SRX_FLUSH
 }
 
+// The same sums for float32 data on the matrix cores (at most 16 states, NC <= 3 blocks of
+// 16 features): four frames are one k-step of v_mfma_f32_16x16x4_f32, A[row = state][k] =
+// gamma[t0 + k][state], B[k][col] = x[t0 + k][16c + col] or its square, so result register r
+// of lane (g, col) is the sum for state 4g + r and feature 16c + col.  The float32
+// accumulators cover one utterance, then fold into float64 registers that stay with the
+// model until it changes; each one-wave workgroup owns a slice of the processing order and
+// of `partial` (layout and fixed-order reduction as above).
+template <int NC>
+__global__ __launch_bounds__(64) void obs_stats_f32_mfma_kernel(
+    const float* __restrict__ X, const float* __restrict__ gamma, const int64_t* __restrict__ off,
+    int64_t U, const int32_t* __restrict__ utt_model, const int64_t* __restrict__ utt_order, int M,
+    int S, int D, double* __restrict__ partial) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x, g = lane >> 4, ul = lane & 15;
+    const int SD = S * D, Q = S + 2 * SD;
+    double* mine = partial + (size_t)blockIdx.x * M * Q;
+    for (int i = lane; i < M * Q; i += 64) mine[i] = 0.0;
+    const int64_t per = (U + gridDim.x - 1) / gridDim.x;
+    const int64_t k0 = blockIdx.x * per;
+    const int64_t k1 = k0 + per < U ? k0 + per : U;
+    double d1[NC][4], d2[NC][4], dp = 0.0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d1[c][r] = d2[c][r] = 0.0;
+    int cur = -1;
+    auto flush = [&](int mm) {
+        if (mm < 0) return;
+        double* dst = mine + (size_t)mm * Q;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int st_ = 4 * g + r, d = 16 * c + ul;
+                if (st_ < S && d < D) {
+                    dst[S + st_ * D + d] += d1[c][r];
+                    dst[S + SD + st_ * D + d] += d2[c][r];
+                }
+                d1[c][r] = d2[c][r] = 0.0;
+            }
+        double p = dp;
+        p += __shfl_xor(p, 16, 64);
+        p += __shfl_xor(p, 32, 64);
+        if (g == 0 && ul < S) dst[ul] += p;
+        dp = 0.0;
+    };
+    // (the slice is zeroed and later updated by different lanes of this one-wave workgroup)
+    __syncthreads();
+    for (int64_t k = k0; k < k1; ++k) {
+        const int64_t u = utt_order ? utt_order[k] : k;
+        if (u < 0) continue;
+        const int m = utt_model ? utt_model[u] : 0;
+        if (m != cur) {
+            flush(cur);
+            cur = m;
+        }
+        const int64_t f0 = off[u], T = off[u + 1] - f0;
+        const bool st_ok = ul < S;
+        auto load = [&](int64_t t0, float& gv, float (&xv)[NC]) {
+            const int64_t t = t0 + g;
+            const bool ok = t < T;
+            const int64_t f = f0 + (ok ? t : 0);
+            gv = ok && st_ok ? gamma[f * S + ul] : 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) xv[c] = ok && 16 * c + ul < D ? X[f * D + 16 * c + ul] : 0.f;
+        };
+        f32x4 o1[NC], o2[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) o1[c] = o2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float ap = 0.f;
+        float ga, xa[NC], gb = 0.f, xb[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) xb[c] = 0.f;
+        if (T > 0) load(0, ga, xa);
+        int64_t folded = 0;
+        for (int64_t t0 = 0; t0 < T; t0 += 4) {
+            if (t0 + 4 < T) load(t0 + 4, gb, xb);
+            ap += ga;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                o1[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, xa[c], o1[c], 0, 0, 0);
+                o2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, xa[c] * xa[c], o2[c], 0, 0, 0);
+            }
+            ga = gb;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) xa[c] = xb[c];
+            // (float32 sums cover at most 4096 frames before they are folded)
+            if (t0 + 4 >= T || t0 + 4 - folded >= 4096) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        d1[c][r] += (double)o1[c][r];
+                        d2[c][r] += (double)o2[c][r];
+                    }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) o1[c] = o2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp += (double)ap;
+                ap = 0.f;
+                folded = t0 + 4;
+            }
+        }
+    }
+    flush(cur);
+}
+
 // Fixed-order sum of the per-workgroup partials into the packed records.
 __global__ void reduce_stats_kernel(const double* __restrict__ part_fb, int n_fb,
                                     const double* __restrict__ part_obs, int n_obs, int M, int S,
@@ -430,27 +536,36 @@ __global__ void reduce_stats_kernel(const double* __restrict__ part_fb, int n_fb
     const srx_stats_layout L(S, D);
     const int P = S * S + S + 2;
     const int Q = S + 2 * S * D;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nth = gridDim.x * blockDim.x;
-    for (int i = tid; i < M * P; i += nth) {
-        const int m = i / P, r = i % P;
+    // one wave per output sum: lane l adds partials l, l + 64, ... in order, then the 64
+    // lane sums are added in a fixed tree
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_wave = (gridDim.x * blockDim.x) >> 6;
+    for (int i = wave; i < M * (P + Q); i += n_wave) {
+        const bool fb = i < M * P;
+        const int k = fb ? i : i - M * P;
+        const double* src = fb ? part_fb : part_obs;
+        const int n = fb ? n_fb : n_obs;
+        const size_t stride = (size_t)M * (fb ? P : Q);
         double s = 0.0;
-        // (fixed order of additions; unrolled so that eight loads are in flight)
-#pragma unroll 8
-        for (int b = 0; b < n_fb; ++b) s += part_fb[(size_t)b * M * P + i];
+        for (int b = lane; b < n; b += 64) s += src[(size_t)b * stride + k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane != 0) continue;
         int64_t dst;
-        if (r < S * S) dst = L.trans + r;
-        else if (r < S * S + S) dst = L.start + (r - S * S);
-        else if (r == S * S + S) dst = L.logprob;
-        else dst = L.nobs;
-        out[(size_t)m * L.size + dst] = s;
-    }
-    for (int i = tid; i < M * Q; i += nth) {
-        const int m = i / Q, r = i % Q;
-        double s = 0.0;
-#pragma unroll 8
-        for (int b = 0; b < n_obs; ++b) s += part_obs[(size_t)b * M * Q + i];
-        const int64_t dst = r < S ? L.post + r : L.obs + (r - S);  // obs2 follows obs
+        int m;
+        if (fb) {
+            m = k / P;
+            const int r = k % P;
+            if (r < S * S) dst = L.trans + r;
+            else if (r < S * S + S) dst = L.start + (r - S * S);
+            else if (r == S * S + S) dst = L.logprob;
+            else dst = L.nobs;
+        } else {
+            m = k / Q;
+            const int r = k % Q;
+            dst = r < S ? L.post + r : L.obs + (r - S);  // obs2 follows obs
+        }
         out[(size_t)m * L.size + dst] = s;
     }
 }
@@ -624,27 +739,42 @@ __global__ __launch_bounds__(64) void viterbi_lane_kernel(
 // replaces it by the posteriors) and the scale factors move four frames at a time.
 // The arithmetic is fb_chain_kernel's: b~ = exp(l - max l), alpha scaled to sum 1,
 // beta with the same factors, gamma = alpha beta normalised (zero rows divide by 1).
-template <int S>
+// STATS: the E-step of small jobs.  The lane also sums xi of its utterance in S x S
+// registers (float32 over one utterance, like the fused kernel over a batch) and adds
+// them, gamma_0, the log-probability and a count to the workgroup's float64 record in
+// LDS -> partial[blockIdx][M][S*S + S + 2], fb_chain_kernel's layout.
+template <int S, bool STATS>
 __global__ __launch_bounds__(64) void fb_lane_kernel(
     const float* __restrict__ loglik, const int64_t* __restrict__ off, int64_t U,
     const int32_t* __restrict__ utt_model, Tables<float> tb, float* __restrict__ lat,
-    float* __restrict__ scale, double* __restrict__ utt_lp) {
-    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= U) return;
-    const int m = utt_model ? utt_model[u] : 0;
-    const int64_t f0 = off[u];
-    const int T_len = (int)(off[u + 1] - f0);
-    if (T_len <= 0) {
-        utt_lp[u] = 0.0;
-        return;
+    float* __restrict__ scale, double* __restrict__ utt_lp, double* __restrict__ partial, int M,
+    const double* __restrict__ A64, const double* __restrict__ pi64) {
+    // (A64 / pi64: read the transition and start probabilities from the float64 model
+    // arrays instead of prepared float32 tables)
+    extern __shared__ __attribute__((aligned(16))) double acc_lds[];
+    constexpr int P = S * S + S + 2;
+    if constexpr (STATS) {
+        for (int i = threadIdx.x; i < M * P; i += blockDim.x) acc_lds[i] = 0.0;
+        __syncthreads();
     }
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = u < U;
+    const int m = valid && utt_model ? utt_model[u] : 0;
+    const int64_t f0 = valid ? off[u] : 0;
+    const int T_len = valid ? (int)(off[u + 1] - f0) : 0;
+    if (T_len <= 0 && valid && utt_lp) utt_lp[u] = 0.0;
+    if (T_len > 0) {
     struct __attribute__((packed, aligned(4))) Rows4 { float v[4 * S]; };   // rows are 4-byte aligned
     struct __attribute__((packed, aligned(4))) Four { float v[4]; };
     float A[S][S];
 #pragma unroll
     for (int i = 0; i < S; ++i)
 #pragma unroll
-        for (int j = 0; j < S; ++j) A[i][j] = tb.A[((size_t)m * S + i) * S + j];
+        for (int j = 0; j < S; ++j)
+            A[i][j] = A64 ? (float)A64[((size_t)m * S + i) * S + j] : tb.A[((size_t)m * S + i) * S + j];
+    float pi[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) pi[j] = pi64 ? (float)pi64[m * S + j] : tb.pi[m * S + j];
     const float* ll = loglik + f0 * S;
     float* la = lat + f0 * S;
     float* sc = scale + f0;
@@ -666,7 +796,7 @@ __global__ __launch_bounds__(64) void fb_lane_kernel(
         const float mx = emis(row, b);
         if (first) {
 #pragma unroll
-            for (int j = 0; j < S; ++j) a[j] = tb.pi[m * S + j] * b[j];
+            for (int j = 0; j < S; ++j) a[j] = pi[j] * b[j];
         } else {
 #pragma unroll
             for (int j = 0; j < S; ++j) {
@@ -719,11 +849,19 @@ __global__ __launch_bounds__(64) void fb_lane_kernel(
 #pragma unroll
         for (int j = 0; j < S; ++j) la[(size_t)t * S + j] = o[j];
     }
-    utt_lp[u] = lp + (double)lpf;
+    lp += (double)lpf;
+    if (utt_lp) utt_lp[u] = lp;
     // ---- backward: frames T-1 .. 0; bb = b~_{t+1} beta_{t+1}
-    float bb[S];
+    float bb[S], gam0[S];
+    float xi[STATS ? S : 1][STATS ? S : 1];
 #pragma unroll
-    for (int j = 0; j < S; ++j) bb[j] = 0.f;
+    for (int j = 0; j < S; ++j) bb[j] = gam0[j] = 0.f;
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < S; ++i)
+#pragma unroll
+            for (int j = 0; j < S; ++j) xi[i][j] = 0.f;
+    }
     auto bwd = [&](bool last, const float* row, const float* arow, float ci, float* out_row) {
         float beta[S];
         if (last) {
@@ -734,7 +872,11 @@ __global__ __launch_bounds__(64) void fb_lane_kernel(
             for (int i = 0; i < S; ++i) {
                 float acc = 0.f;
 #pragma unroll
-                for (int j = 0; j < S; ++j) acc += A[i][j] * bb[j];
+                for (int j = 0; j < S; ++j) {
+                    const float w = A[i][j] * bb[j];
+                    acc += w;
+                    if constexpr (STATS) xi[i][j] += arow[i] * w;
+                }
                 beta[i] = acc * ci;
             }
         }
@@ -751,6 +893,7 @@ __global__ __launch_bounds__(64) void fb_lane_kernel(
 #pragma unroll
         for (int i = 0; i < S; ++i) {
             out_row[i] = g[i] * gi;
+            if constexpr (STATS) gam0[i] = out_row[i];
             bb[i] = b[i] * beta[i];
         }
     };
@@ -792,6 +935,24 @@ __global__ __launch_bounds__(64) void fb_lane_kernel(
         last = false;
 #pragma unroll
         for (int j = 0; j < S; ++j) la[(size_t)t * S + j] = o[j];
+    }
+    if constexpr (STATS) {
+        double* a = acc_lds + (size_t)m * P;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+#pragma unroll
+            for (int j = 0; j < S; ++j)
+                if (T_len > 1) atomicAdd(&a[i * S + j], (double)xi[i][j]);
+            atomicAdd(&a[S * S + i], (double)gam0[i]);
+        }
+        atomicAdd(&a[S * S + S], lp);
+        atomicAdd(&a[S * S + S + 1], 1.0);
+    }
+    }
+    if constexpr (STATS) {
+        __syncthreads();
+        double* dst = partial + (size_t)blockIdx.x * M * P;
+        for (int i = threadIdx.x; i < M * P; i += blockDim.x) dst[i] = acc_lds[i];
     }
 }
 
@@ -1019,8 +1180,9 @@ int posteriors_t(srx_context* h, const void* X, const int64_t* off, int64_t U, i
             const dim3 grid((unsigned)((U + bs - 1) / bs));
 #define SRX_CASE(s_)                                                                       \
     if (S == s_)                                                                           \
-        hipLaunchKernelGGL((fb_lane_kernel<s_>), grid, dim3(bs), 0, st, (const float*)ll,  \
-                           off, U, utt_model, tb, (float*)gamma, (float*)sc, lp);
+        hipLaunchKernelGGL((fb_lane_kernel<s_, false>), grid, dim3(bs), 0, st, (const float*)ll, \
+                           off, U, utt_model, tb, (float*)gamma, (float*)sc, lp, (double*)nullptr, M, \
+                           (const double*)nullptr, (const double*)nullptr);
             SRX_CASE(1) SRX_CASE(2) SRX_CASE(3) SRX_CASE(4) SRX_CASE(5) SRX_CASE(6) SRX_CASE(7)
             SRX_CASE(8)
 #undef SRX_CASE
@@ -1096,8 +1258,62 @@ int estep_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_
     else OBS(16);
 #undef OBS
     // one thread per output sum
-    const int64_t n_out = (int64_t)M * (P > Q ? P : Q);
-    const int g_red = (int)std::min<int64_t>((n_out + kBlock - 1) / kBlock, 4096);
+    const int64_t n_out = (int64_t)M * (P + Q);                  // one wave per output sum
+    const int g_red = (int)std::min<int64_t>((n_out * 64 + kBlock - 1) / kBlock, 4096);
+    hipLaunchKernelGGL(reduce_stats_kernel, dim3(g_red), dim3(kBlock), 0, st, (const double*)part, g_fb,
+                       (const double*)part_obs, g_obs, M, S, D, out_stats);
+    SRX_HIP(hipGetLastError());
+    return SRX_OK;
+}
+
+// E-step of small float32 jobs with at most 8 states: matrix-core emission of every frame
+// at once, then ONE LANE per utterance for the two recursions (a few dozen instructions
+// per frame where the fused kernel spends 72 matrix instructions per step of a wave that a
+// small job cannot fill), then the observation sums over all frames.  A job this path does
+// not want returns SRX_EUNSUPPORTED.
+int estep_lane(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
+               const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* md,
+               double* out_stats, hipStream_t st) {
+    const int M = md->n_models, S = md->n_states, D = md->n_features;
+    const bool asked = h->estep_path == SRX_ESTEP_LANE;      // any number of utterances then
+    // measured crossovers against the fused kernel (utterances of 60 to 240 frames): 8192
+    // utterances for 3 states, about 6000 for 5, 4096 for 8
+    const int64_t max_utts = S <= 4 ? 8192 : (S <= 6 ? 4096 : 3072);
+    const int P = S * S + S + 2, Q = S + 2 * S * D;
+    const size_t lds = sizeof(double) * (size_t)M * P;
+    if (S > 8 || D > 48 || U <= 0 || (U > max_utts && !asked) || n_frames <= 0 || lds > 32 * 1024)
+        return SRX_EUNSUPPORTED;
+    Tables<float> tb = {};           // (the lane kernel takes A and pi from the float64 model arrays)
+    int rc;
+    float *ll, *lat, *sc;
+    if ((rc = srx_ws_ensure(h, WS_LOGLIK, sizeof(float) * (size_t)n_frames * S, (void**)&ll))) return rc;
+    if ((rc = srx_ws_ensure(h, WS_LATTICE, sizeof(float) * (size_t)n_frames * S, (void**)&lat))) return rc;
+    if ((rc = srx_ws_ensure(h, WS_SCALE, sizeof(float) * (size_t)n_frames, (void**)&sc))) return rc;
+    const int g_fb = (int)((U + 63) / 64);
+    const int g_obs = (int)std::min<int64_t>(U, 1024);      // one-wave workgroups, a slice of utterances each
+    double* part;
+    if ((rc = srx_ws_ensure(h, WS_PARTIAL, sizeof(double) * ((size_t)g_fb * M * P + (size_t)g_obs * M * Q),
+                            (void**)&part)))
+        return rc;
+    double* part_obs = part + (size_t)g_fb * M * P;
+    rc = srx_mfma_emission_utt_f32(h, X, off, U, n_frames, utt_model, md, ll, st);
+    if (rc) return rc;               // (SRX_EUNSUPPORTED included: the caller goes on to the other paths)
+#define SRX_CASE(s_)                                                                           \
+    if (S == s_)                                                                               \
+        hipLaunchKernelGGL((fb_lane_kernel<s_, true>), dim3(g_fb), dim3(64), lds, st, (const float*)ll, \
+                           off, U, utt_model, tb, lat, sc, (double*)nullptr, part, M, md->transmat,     \
+                           md->startprob);
+    SRX_CASE(1) SRX_CASE(2) SRX_CASE(3) SRX_CASE(4) SRX_CASE(5) SRX_CASE(6) SRX_CASE(7) SRX_CASE(8)
+#undef SRX_CASE
+#define OBS(NC)                                                                                   \
+    hipLaunchKernelGGL((obs_stats_f32_mfma_kernel<NC>), dim3(g_obs), dim3(64), 0, st, (const float*)X, \
+                       (const float*)lat, off, U, utt_model, utt_order, M, S, D, part_obs)
+    if (D <= 16) OBS(1);
+    else if (D <= 32) OBS(2);
+    else OBS(3);
+#undef OBS
+    const int64_t n_out = (int64_t)M * (P + Q);                  // one wave per output sum
+    const int g_red = (int)std::min<int64_t>((n_out * 64 + kBlock - 1) / kBlock, 4096);
     hipLaunchKernelGGL(reduce_stats_kernel, dim3(g_red), dim3(kBlock), 0, st, (const double*)part, g_fb,
                        (const double*)part_obs, g_obs, M, S, D, out_stats);
     SRX_HIP(hipGetLastError());
@@ -1105,6 +1321,12 @@ int estep_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_
 }
 
 }  // namespace
+
+int srx_lane_estep(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
+                   const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* md,
+                   double* out_stats, hipStream_t st) {
+    return estep_lane(h, X, off, U, n_frames, utt_model, utt_order, md, out_stats, st);
+}
 
 __global__ void srx_fill_slices(int64_t* offs, int64_t n_slices, int64_t slice, int64_t n_frames) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -419,19 +419,21 @@ __global__ void emission_f32_prep_kernel(srx_models_t md, int RQ, float* W, floa
         }
         W[i] = v;
     }
-    for (int row = tid; row < M * 16; row += nth) {
+    // constants: one wave per row, lanes over features (a serial sum of D float64
+    // logarithms per row would be most of this kernel's time)
+    const int wave = tid >> 6, lane = tid & 63, n_wave = nth >> 6;
+    for (int row = wave; row < M * 16; row += n_wave) {
         const int m = row >> 4, s_ = row & 15;
-        float v = 0.f;
-        if (s_ < S) {
-            double acc = D * 1.8378770664093453;
-            for (int d = 0; d < D; ++d) {
+        double acc = 0.0;
+        if (s_ < S)
+            for (int d = lane; d < D; d += 64) {
                 const size_t k = ((size_t)m * S + s_) * D + d;
                 const double var = fmax(md.covars[k], 2.2250738585072014e-308);
                 acc += log(var) + md.means[k] * md.means[k] / var;
             }
-            v = (float)(-0.5 * acc);
-        }
-        cst[row] = v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) cst[row] = s_ < S ? (float)(-0.5 * (acc + D * 1.8378770664093453)) : 0.f;
     }
 }
 

@@ -24,6 +24,7 @@ struct srx_context {
     int device;
     int n_cu;
     int exact_f32;   // SRX_OPT_EXACT_F32: keep the float32 paths on exact-f32 matrix instructions
+    int estep_path;  // SRX_OPT_ESTEP_PATH
     void* ws[WS_NUM];
     size_t ws_bytes[WS_NUM];
     void* static_scratch;   // this device's copy of the fixed table array (api.hip)
@@ -107,6 +108,12 @@ int srx_generic_estep(srx_context* h, const void* X, int dtype, const int64_t* o
                       double* out_stats, hipStream_t st);
 int srx_generic_mstep(srx_context* h, const double* stats, const srx_priors_t* pr,
                       int mode, const srx_models_t* models, hipStream_t st);
+// Float32 E-step of small jobs (at most 8 states, a few thousand utterances, or any number
+// when the context's SRX_OPT_ESTEP_PATH asks for it): one lane per utterance;
+// SRX_EUNSUPPORTED for every other job.
+int srx_lane_estep(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
+                   const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* md,
+                   double* out_stats, hipStream_t st);
 
 // Implemented in score_mfma.hip: returns SRX_EUNSUPPORTED when the shape has no
 // matrix-core kernel, so the caller can take the generic path.

@@ -70,6 +70,12 @@ class Context:
         (default): split-bf16 emission contraction."""
         check(lib.srx_set_option(self._h, _lib.SRX_OPT_EXACT_F32, int(bool(on))), "srx_set_option")
 
+    def set_estep_path(self, path):
+        """Kernels of the float32 E-step: "auto" (one lane per utterance for small jobs of at
+        most 8 states, the fused matrix-core kernel otherwise), "fused" or "lane"."""
+        code = {"auto": _lib.SRX_ESTEP_AUTO, "fused": _lib.SRX_ESTEP_FUSED, "lane": _lib.SRX_ESTEP_LANE}[path]
+        check(lib.srx_set_option(self._h, _lib.SRX_OPT_ESTEP_PATH, code), "srx_set_option")
+
     def workspace_bytes(self):
         return int(lib.srx_workspace_bytes(self._h))
 

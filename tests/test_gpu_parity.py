@@ -61,10 +61,21 @@ def test_emission_and_score_match_reference(sra, ctx, hmm_golden, case, dtype, t
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("dtype,generic", [("float64", False), ("float32", False), ("float32", True)])
-def test_estep_and_mstep_match_reference(sra, ctx, hmm_golden, case, dtype, generic):
-    """float32 + generic=False is the fused matrix-core E-step, the other two
-    go through the shape-generic kernels."""
+@pytest.mark.parametrize("dtype,path", [("float64", "auto"), ("float32", "fused"), ("float32", "lane"),
+                                        ("float32", "generic")])
+def test_estep_and_mstep_match_reference(sra, ctx, hmm_golden, case, dtype, path):
+    """float32: the fused matrix-core E-step, the lane-per-utterance E-step of small jobs (at
+    most 8 states; larger models fall through to the fused kernel) and the shape-generic
+    kernels; float64: the validation kernels."""
+    generic = path == "generic"
+    ctx.set_estep_path("auto" if generic else path)
+    try:
+        _check_estep_and_mstep(sra, ctx, hmm_golden, case, dtype, generic)
+    finally:
+        ctx.set_estep_path("auto")
+
+
+def _check_estep_and_mstep(sra, ctx, hmm_golden, case, dtype, generic):
     g, p = hmm_golden, case + "_"
     prm = golden_params(g, case)
     bank = _bank(sra, ctx, [prm])
@@ -165,11 +176,16 @@ def test_multi_model_bank_and_ragged_edges(sra, ctx):
         np.testing.assert_allclose(got[m]["logprob"], lps.sum(), rtol=1e-10)
         for k in ("start", "trans", "post", "obs", "obs**2"):
             np.testing.assert_allclose(got[m][k], st[k], rtol=1e-8, atol=1e-10)
-    # the same batch through the fused float32 E-step, in label order and unsorted
+    # the same batch through both float32 E-steps (fused matrix-core kernel, one lane per
+    # utterance), in label order and unsorted
     d32 = sra.Ragged(ctx, X, lengths, dtype="float32")
     umd = ctx.tensor(um)
-    for order in (tr.utt_order, None):
-        got32 = bank.unpack_stats(bank.estep(d32, umd, order))
+    for path, order in (("fused", tr.utt_order), ("fused", None), ("lane", tr.utt_order), ("lane", None)):
+        ctx.set_estep_path(path)
+        try:
+            got32 = bank.unpack_stats(bank.estep(d32, umd, order))
+        finally:
+            ctx.set_estep_path("auto")
         for m in range(M):
             sel = [u for u in range(len(lengths)) if um[u] == m]
             Xm = np.vstack([X[off[u]:off[u + 1]] for u in sel])
