@@ -119,7 +119,9 @@ int srx_destroy(srx_handle_t h);
  * default) takes one lane per utterance for small jobs (at most 8 states and, by the
  * number of states, 3072 to 8192 utterances) and the fused matrix-core kernel otherwise; SRX_ESTEP_FUSED (1) and
  * SRX_ESTEP_LANE (2) ask for one of the two wherever its limits allow (tests, timing).
- * The results agree to float32 rounding. */
+ * The results agree to float32 rounding.  SRX_F64 data: small jobs take one lane per
+ * utterance too (at most 4 states, 4096 utterances); SRX_ESTEP_FUSED keeps them on the
+ * sub-wave chain kernels every other float64 job runs on. */
 enum srx_option { SRX_OPT_EXACT_F32 = 1, SRX_OPT_ESTEP_PATH = 2 };
 enum srx_estep_path { SRX_ESTEP_AUTO = 0, SRX_ESTEP_FUSED = 1, SRX_ESTEP_LANE = 2 };
 int srx_set_option(srx_handle_t h, int option, int value);

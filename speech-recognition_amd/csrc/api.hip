@@ -391,6 +391,11 @@ static int estep_common(srx_handle_t h, const void* X, int dtype, const int64_t*
                              out_stats, (hipStream_t)stream);
         if (rc != SRX_EUNSUPPORTED) return rc;
     }
+    if (allow_fused && dtype == SRX_F64 && h->estep_path != SRX_ESTEP_FUSED) {
+        rc = srx_lane_estep_f64(h, X, utt_offsets, n_utts, n_frames, utt_model, utt_order, models, out_stats,
+                                (hipStream_t)stream);
+        if (rc != SRX_EUNSUPPORTED) return rc;
+    }
     return srx_generic_estep(h, X, dtype, utt_offsets, n_utts, n_frames, utt_model, utt_order,
                              models, out_stats, (hipStream_t)stream);
 }

@@ -72,12 +72,19 @@ __global__ void prep_kernel(srx_models_t md, T* mu, T* hinv, T* cst, T* A, T* pi
         mu[i] = (T)md.means[i];
         hinv[i] = (T)(-0.5 / v);
     }
-    for (int i = tid; i < M * S; i += nth) {
+    // constants: one wave per state, lanes over features (a serial sum of D float64
+    // logarithms per state would be most of this kernel's time)
+    const int wave = tid >> 6, lane = tid & 63, n_wave = nth >> 6;
+    for (int i = wave; i < M * S; i += n_wave) {
         double acc = 0.0;
-        for (int d = 0; d < D; ++d) acc += log(fmax(md.covars[(size_t)i * D + d], kTiny));
-        cst[i] = (T)(-0.5 * (D * 1.8378770664093453 + acc));
-        pi[i] = (T)md.startprob[i];
-        logpi[i] = (T)log(md.startprob[i]);
+        for (int d = lane; d < D; d += 64) acc += log(fmax(md.covars[(size_t)i * D + d], kTiny));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) {
+            cst[i] = (T)(-0.5 * (D * 1.8378770664093453 + acc));
+            pi[i] = (T)md.startprob[i];
+            logpi[i] = (T)log(md.startprob[i]);
+        }
     }
     for (int i = tid; i < M * S * S; i += nth) {
         A[i] = (T)md.transmat[i];
@@ -956,6 +963,205 @@ __global__ __launch_bounds__(64) void fb_lane_kernel(
     }
 }
 
+// Float64 E-step of small jobs.  A pass over all frames first replaces every row of
+// log-densities by b~ = exp(l - max l) and keeps the maxima (the software float64
+// exponentials run in parallel there instead of inside the recursion); then one lane per
+// utterance runs the two recursions on b~, like fb_lane_kernel<S, true> -- product of the
+// scale factors as mantissa and exponent (LogProduct), one logarithm per utterance.
+__global__ void shift_exp_f64_kernel(double* __restrict__ ll, int64_t n_frames, int S,
+                                     double* __restrict__ mx_out) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    double* row = ll + f * S;
+    double mx = row[0];
+    for (int j = 1; j < S; ++j) mx = fmax(mx, row[j]);
+    for (int j = 0; j < S; ++j) row[j] = exp(row[j] - mx);
+    mx_out[f] = mx;
+}
+
+template <int S>
+__global__ __launch_bounds__(64) void fb_lane_f64_kernel(
+    const double* __restrict__ btil, const double* __restrict__ mxv, const int64_t* __restrict__ off,
+    int64_t U, const int32_t* __restrict__ utt_model, const double* __restrict__ A64,
+    const double* __restrict__ pi64, double* __restrict__ lat, double* __restrict__ scale,
+    double* __restrict__ partial, int M) {
+    extern __shared__ __attribute__((aligned(16))) double acc_lds[];
+    constexpr int P = S * S + S + 2;
+    for (int i = threadIdx.x; i < M * P; i += blockDim.x) acc_lds[i] = 0.0;
+    __syncthreads();
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = u < U;
+    const int m = valid && utt_model ? utt_model[u] : 0;
+    const int64_t f0 = valid ? off[u] : 0;
+    const int T_len = valid ? (int)(off[u + 1] - f0) : 0;
+    if (T_len > 0) {
+        struct Rows4 { double v[4 * S]; };
+        struct Four { double v[4]; };
+        double A[S][S];
+#pragma unroll
+        for (int i = 0; i < S; ++i)
+#pragma unroll
+            for (int j = 0; j < S; ++j) A[i][j] = A64[((size_t)m * S + i) * S + j];
+        const double* bt = btil + f0 * S;
+        const double* mx = mxv + f0;
+        double* la = lat + f0 * S;
+        double* sc = scale + f0;
+        // ---- forward (rows move four frames at a time, the next four requested before
+        // the current four are used)
+        double alpha[S];
+        LogProduct lpp;
+        auto fwd = [&](bool first, const double* row, double mxt, double* out_row) {
+            double a[S], c = 0.0;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                double acc;
+                if (first) {
+                    acc = pi64[m * S + j];
+                } else {
+                    acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < S; ++i) acc += alpha[i] * A[i][j];
+                }
+                a[j] = acc * row[j];
+                c += a[j];
+            }
+            lpp.step(mxt, c);
+            const double ci = 1.0 / c;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                alpha[j] = a[j] * ci;
+                out_row[j] = alpha[j];
+            }
+            return ci;
+        };
+        {
+            double row[S], o[S];
+#pragma unroll
+            for (int j = 0; j < S; ++j) row[j] = bt[j];
+            sc[0] = fwd(true, row, mx[0], o);
+#pragma unroll
+            for (int j = 0; j < S; ++j) la[j] = o[j];
+        }
+        int t = 1;
+        Rows4 cur, nxt;
+        Four mcur, mnxt;
+        if (t + 4 <= T_len) {
+            cur = *(const Rows4*)(bt + (size_t)t * S);
+            mcur = *(const Four*)(mx + t);
+        }
+        for (; t + 4 <= T_len; t += 4) {
+            if (t + 8 <= T_len) {
+                nxt = *(const Rows4*)(bt + (size_t)(t + 4) * S);
+                mnxt = *(const Four*)(mx + t + 4);
+            }
+            Rows4 o;
+            Four c4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c4.v[k] = fwd(false, cur.v + k * S, mcur.v[k], o.v + k * S);
+            *(Rows4*)(la + (size_t)t * S) = o;
+            *(Four*)(sc + t) = c4;
+            cur = nxt;
+            mcur = mnxt;
+        }
+        for (; t < T_len; ++t) {
+            double row[S], o[S];
+#pragma unroll
+            for (int j = 0; j < S; ++j) row[j] = bt[(size_t)t * S + j];
+            sc[t] = fwd(false, row, mx[t], o);
+#pragma unroll
+            for (int j = 0; j < S; ++j) la[(size_t)t * S + j] = o[j];
+        }
+        const double lp = lpp.value();
+        // ---- backward: bb = b~_{t+1} beta_{t+1}
+        double bb[S], gam0[S], xi[S][S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            bb[i] = gam0[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < S; ++j) xi[i][j] = 0.0;
+        }
+        auto bwd = [&](bool last, const double* row, const double* arow, double ci, double* out_row) {
+            double beta[S], g[S], gs = 0.0;
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                if (last) {
+                    beta[i] = ci;
+                } else {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < S; ++j) {
+                        const double w = A[i][j] * bb[j];
+                        acc += w;
+                        xi[i][j] += arow[i] * w;
+                    }
+                    beta[i] = acc * ci;
+                }
+                g[i] = arow[i] * beta[i];
+                gs += g[i];
+            }
+            if (gs == 0.0) gs = 1.0;                  // utils.normalize: zero rows divide by 1
+            const double gi = 1.0 / gs;
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                out_row[i] = g[i] * gi;
+                gam0[i] = out_row[i];
+                bb[i] = row[i] * beta[i];
+            }
+        };
+        t = T_len - 1;
+        bool last = true;
+        Rows4 lr, ar, lr_n, ar_n;
+        Four c4, c4_n;
+        if (t >= 3) {
+            lr = *(const Rows4*)(bt + (size_t)(t - 3) * S);
+            ar = *(const Rows4*)(la + (size_t)(t - 3) * S);
+            c4 = *(const Four*)(sc + t - 3);
+        }
+        for (; t >= 3; t -= 4) {
+            if (t >= 7) {
+                lr_n = *(const Rows4*)(bt + (size_t)(t - 7) * S);
+                ar_n = *(const Rows4*)(la + (size_t)(t - 7) * S);
+                c4_n = *(const Four*)(sc + t - 7);
+            }
+            Rows4 o;
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {
+                bwd(last, lr.v + k * S, ar.v + k * S, c4.v[k], o.v + k * S);
+                last = false;
+            }
+            *(Rows4*)(la + (size_t)(t - 3) * S) = o;
+            lr = lr_n;
+            ar = ar_n;
+            c4 = c4_n;
+        }
+        for (; t >= 0; --t) {
+            double row[S], ar1[S], o[S];
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                row[j] = bt[(size_t)t * S + j];
+                ar1[j] = la[(size_t)t * S + j];
+            }
+            bwd(last, row, ar1, sc[t], o);
+            last = false;
+#pragma unroll
+            for (int j = 0; j < S; ++j) la[(size_t)t * S + j] = o[j];
+        }
+        double* a = acc_lds + (size_t)m * P;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+#pragma unroll
+            for (int j = 0; j < S; ++j)
+                if (T_len > 1) atomicAdd(&a[i * S + j], xi[i][j]);
+            atomicAdd(&a[S * S + i], gam0[i]);
+        }
+        atomicAdd(&a[S * S + S], lp);
+        atomicAdd(&a[S * S + S + 1], 1.0);
+    }
+    __syncthreads();
+    double* dst = partial + (size_t)blockIdx.x * M * P;
+    for (int i = threadIdx.x; i < M * P; i += blockDim.x) dst[i] = acc_lds[i];
+}
+
 // One workgroup per model.
 __global__ void mstep_kernel(const double* __restrict__ stats, srx_priors_t pr, int mode,
                              srx_models_t md) {
@@ -1320,7 +1526,57 @@ int estep_lane(srx_context* h, const void* X, const int64_t* off, int64_t U, int
     return SRX_OK;
 }
 
+int estep_lane_f64(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
+                   const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* md,
+                   double* out_stats, hipStream_t st) {
+    const int M = md->n_models, S = md->n_states, D = md->n_features;
+    const bool asked = h->estep_path == SRX_ESTEP_LANE;
+    const int P = S * S + S + 2, Q = S + 2 * S * D;
+    const size_t lds = sizeof(double) * (size_t)M * P;
+    // (5 to 8 states: the sub-wave chain kernel is faster than one float64 lane)
+    if (S > (asked ? 8 : 4) || D > 48 || U <= 0 || (U > 4096 && !asked) || n_frames <= 0 || lds > 32 * 1024)
+        return SRX_EUNSUPPORTED;
+    int rc;
+    double *ll, *lat, *sc;
+    if ((rc = srx_ws_ensure(h, WS_LOGLIK, sizeof(double) * (size_t)n_frames * S, (void**)&ll))) return rc;
+    if ((rc = srx_ws_ensure(h, WS_LATTICE, sizeof(double) * (size_t)n_frames * S, (void**)&lat))) return rc;
+    if ((rc = srx_ws_ensure(h, WS_SCALE, sizeof(double) * (size_t)n_frames * 2, (void**)&sc))) return rc;
+    double* mxv = sc + n_frames;
+    const int g_fb = (int)((U + 63) / 64);
+    const int g_obs = (int)std::min<int64_t>(U, 1024);
+    double* part;
+    if ((rc = srx_ws_ensure(h, WS_PARTIAL, sizeof(double) * ((size_t)g_fb * M * P + (size_t)g_obs * M * Q),
+                            (void**)&part)))
+        return rc;
+    double* part_obs = part + (size_t)g_fb * M * P;
+    rc = srx_mfma_emission_utt_f64(h, X, off, U, n_frames, utt_model, md, ll, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(shift_exp_f64_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, st, ll,
+                       n_frames, S, mxv);
+#define SRX_CASE(s_)                                                                              \
+    if (S == s_)                                                                                  \
+        hipLaunchKernelGGL((fb_lane_f64_kernel<s_>), dim3(g_fb), dim3(64), lds, st, (const double*)ll, \
+                           (const double*)mxv, off, U, utt_model, md->transmat, md->startprob, lat, sc, \
+                           part, M);
+    SRX_CASE(1) SRX_CASE(2) SRX_CASE(3) SRX_CASE(4) SRX_CASE(5) SRX_CASE(6) SRX_CASE(7) SRX_CASE(8)
+#undef SRX_CASE
+    rc = srx_mfma_obs_stats_f64(h, X, lat, off, U, utt_model, utt_order, md, part_obs, g_obs, st);
+    if (rc) return rc;
+    const int64_t n_out = (int64_t)M * (P + Q);
+    const int g_red = (int)std::min<int64_t>((n_out * 64 + kBlock - 1) / kBlock, 4096);
+    hipLaunchKernelGGL(reduce_stats_kernel, dim3(g_red), dim3(kBlock), 0, st, (const double*)part, g_fb,
+                       (const double*)part_obs, g_obs, M, S, D, out_stats);
+    SRX_HIP(hipGetLastError());
+    return SRX_OK;
+}
+
 }  // namespace
+
+int srx_lane_estep_f64(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
+                       const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* md,
+                       double* out_stats, hipStream_t st) {
+    return estep_lane_f64(h, X, off, U, n_frames, utt_model, utt_order, md, out_stats, st);
+}
 
 int srx_lane_estep(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
                    const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* md,

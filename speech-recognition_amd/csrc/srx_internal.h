@@ -114,6 +114,10 @@ int srx_generic_mstep(srx_context* h, const double* stats, const srx_priors_t* p
 int srx_lane_estep(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
                    const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* md,
                    double* out_stats, hipStream_t st);
+// The same for float64 data (b~ of every frame exponentiated in a pass of its own).
+int srx_lane_estep_f64(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
+                       const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* md,
+                       double* out_stats, hipStream_t st);
 
 // Implemented in score_mfma.hip: returns SRX_EUNSUPPORTED when the shape has no
 // matrix-core kernel, so the caller can take the generic path.

@@ -61,12 +61,13 @@ def test_emission_and_score_match_reference(sra, ctx, hmm_golden, case, dtype, t
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("dtype,path", [("float64", "auto"), ("float32", "fused"), ("float32", "lane"),
-                                        ("float32", "generic")])
+@pytest.mark.parametrize("dtype,path", [("float64", "fused"), ("float64", "lane"), ("float32", "fused"),
+                                        ("float32", "lane"), ("float32", "generic")])
 def test_estep_and_mstep_match_reference(sra, ctx, hmm_golden, case, dtype, path):
     """float32: the fused matrix-core E-step, the lane-per-utterance E-step of small jobs (at
     most 8 states; larger models fall through to the fused kernel) and the shape-generic
-    kernels; float64: the validation kernels."""
+    kernels; float64: the sub-wave chain kernels ("fused" = no lane path) and the
+    lane-per-utterance E-step."""
     generic = path == "generic"
     ctx.set_estep_path("auto" if generic else path)
     try:

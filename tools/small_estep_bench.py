@@ -21,7 +21,8 @@ for (M, S, D, U) in shapes:
     bank = sra.HMMBank(ctx, rng.dirichlet(np.ones(S), size=M), rng.dirichlet(np.ones(S), size=(M, S)),
                        rng.standard_normal((M, S, D)), rng.uniform(0.5, 1.5, (M, S, D)))
     variants = (("float32", "auto", False), ("float32", "fused", False), ("float32", "lane", False),
-                ("float32", "auto", True), ("float64", "auto", False))
+                ("float32", "auto", True), ("float64", "auto", False), ("float64", "fused", False),
+                ("float64", "lane", False))
     if paths:
         variants = tuple(("float32", q, False) for q in paths.split(","))
     for dtype, path, generic in variants[:1] if only else variants:
