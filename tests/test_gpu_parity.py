@@ -776,6 +776,61 @@ def test_offset_features_stay_within_the_expanded_form_bound(sra, ctx):
     assert (ex <= 16 * 2.0 ** -23 * mag).all()
 
 
+@pytest.mark.parametrize("M,S,D", [(1, 1, 1), (6, 3, 26), (5, 2, 9), (40, 4, 13), (7, 5, 48), (3, 6, 17),
+                                   (9, 7, 33), (6, 8, 39)])
+def test_small_job_estep_paths_agree_with_oracle(sra, ctx, M, S, D):
+    """The lane-per-utterance E-step of small jobs (float32 up to 8 states, float64 up to 4 by
+    default, any of them when asked for) on ragged batches with empty and one-frame
+    utterances, a model without utterances, 130 utterances (three workgroups of the lane
+    kernel, the last one partly empty): per-model statistics against the oracle, and against
+    the other kernels for the same dtype."""
+    rng = np.random.default_rng(1000 * M + 10 * S + D)
+    prms = [ho.random_params(rng, S, D) for _ in range(M)]
+    U = 130
+    lengths = rng.integers(1, 90, size=U)
+    lengths[[3, 64, 129]] = 0
+    lengths[[5, 70]] = 1
+    lengths[7] = 2
+    um = rng.integers(0, M, size=U).astype(np.int32)
+    if M > 2:
+        um[um == 1] = 0                                   # model 1 trains on nothing
+    X = rng.standard_normal((int(lengths.sum()), D))
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    bank = _bank(sra, ctx, prms)
+    want = []
+    for m in range(M):
+        sel = [u for u in range(U) if um[u] == m and lengths[u] > 0]
+        if not sel:
+            want.append(None)
+            continue
+        Xm = np.vstack([X[off[u]:off[u + 1]] for u in sel])
+        st, lps = ho.estep(prms[m], Xm, [int(lengths[u]) for u in sel], loops=False)
+        want.append((st, float(np.sum(lps)), len(sel)))
+    umd = ctx.tensor(um)
+    res = {}
+    for dtype, tol in (("float32", 2e-5), ("float64", 1e-9)):
+        data = sra.Ragged(ctx, X, lengths, dtype=dtype)
+        for path in ("lane", "fused"):
+            ctx.set_estep_path(path)
+            try:
+                raw = bank.estep(data, umd).cpu().numpy()
+            finally:
+                ctx.set_estep_path("auto")
+            res[dtype, path] = raw
+            got = bank.unpack_stats(ctx.tensor(raw))
+            for m in range(M):
+                if want[m] is None:
+                    assert got[m]["nobs"] == 0 and got[m]["logprob"] == 0.0
+                    continue
+                st, lp, n = want[m]
+                assert got[m]["nobs"] == n               # (empty utterances are not counted)
+                assert abs(got[m]["logprob"] - lp) <= tol * abs(lp)
+                for k in ("start", "trans", "post", "obs", "obs**2"):
+                    np.testing.assert_allclose(got[m][k], st[k], rtol=tol, atol=tol * max(1.0, np.abs(st[k]).max()))
+        scale = np.abs(res[dtype, "fused"]).max()
+        assert np.abs(res[dtype, "lane"] - res[dtype, "fused"]).max() <= 2 * tol * scale
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_estep_without_utterances_or_frames(sra, ctx, dtype):
     """No utterance at all, and utterances that are all empty: the statistics are zeros (the
