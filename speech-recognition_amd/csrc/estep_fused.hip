@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
     const int32_t* __restrict__ utt_model, const int64_t* __restrict__ utt_order, int M, int S,
     int D, FusedTables tb, const int64_t* __restrict__ batch_base, float* __restrict__ lat,
     float* __restrict__ scale, double* __restrict__ replicas, int rec_size,
-    float* __restrict__ post_out, double* __restrict__ post_lp) {
+    float* __restrict__ post_out, double* __restrict__ post_lp, unsigned long long* __restrict__ queue) {
     constexpr int DP = 16 * RQ + 8 * H;   // padded feature count
     constexpr int KW = 8 * RQ + 4 * H;    // emission k-steps
     constexpr int XS = frame_tile_stride(DP);
@@ -206,7 +206,18 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
 #pragma unroll
     for (int q = 0; q < 4; ++q) { atop[q] = aop[q] = 0.f; c0[q] = 0.f; pi4[q] = 0.f; }
 
-    for (int64_t k = k0; k < k1; ++k) {
+    // With a `queue` (a zeroed counter) the batches are handed out on demand: the first to
+    // every wave by its index, the following ones in the order the waves ask for them, so a
+    // wave that runs slower, or draws longer utterances, takes fewer, and the grid ends
+    // together.  Without one every wave takes a fixed run of batches.  Every wave leaves the
+    // loop when the batches run out.
+    const bool on_demand = queue != nullptr;
+    int64_t k = on_demand ? wid : k0;
+    const int64_t k_end = on_demand ? n_groups : k1;
+    while (k < k_end) {
+        // (the next batch is asked for now; the answer is needed when this one is done)
+        unsigned long long ticket = 0;
+        if (on_demand && lane == 0) ticket = atomicAdd(queue, 1ull);
         const int64_t e = k * 16 + ul;
         // (U counts the entries of the visiting order here; a negative entry is an empty lane)
         const int64_t u_raw = e < U ? (utt_order ? utt_order[e] : e) : -1;
@@ -540,6 +551,13 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
             }
             wave_sync();
         }
+        if (on_demand) {
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ticket);
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(ticket >> 32));
+            k = n_waves + (int64_t)(((unsigned long long)hi << 32) | lo);
+        } else {
+            ++k;
+        }
     }
 }
 
@@ -605,7 +623,8 @@ template <int RQ, int H, int NTX, bool POST = false>
 int launch(srx_context* h, const float* X, const int64_t* off, int64_t U, int64_t n_frames,
            const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* md,
            FusedTables tb, const int64_t* batch_base, float* lat, float* scale, double* replicas,
-           int rec_size, hipStream_t st, float* post_out = nullptr, double* post_lp = nullptr) {
+           int rec_size, hipStream_t st, float* post_out = nullptr, double* post_lp = nullptr,
+           unsigned long long* queue = nullptr) {
     const size_t lds = POST ? 0 : sizeof(float) * 2 * (3 * 256 + 16 * frame_tile_stride(16 * RQ + 8 * H)) * kWavesPerBlock;
     auto kern = estep_fused_kernel<RQ, H, NTX, POST>;
     SRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -618,7 +637,7 @@ int launch(srx_context* h, const float* X, const int64_t* off, int64_t U, int64_
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kWavesPerBlock), lds, st, X, off, U,
                        n_frames, utt_model, utt_order, md->n_models, md->n_states, md->n_features,
-                       tb, batch_base, lat, scale, replicas, rec_size, post_out, post_lp);
+                       tb, batch_base, lat, scale, replicas, rec_size, post_out, post_lp, queue);
     SRX_HIP(hipGetLastError());
     return SRX_OK;
 }
@@ -752,9 +771,11 @@ int srx_fused_estep(srx_context* h, const void* X, const int64_t* off, int64_t U
     double* replicas;
     if ((rc = srx_ws_ensure(h, WS_LATTICE, sizeof(float) * (size_t)n_frames * 16, (void**)&lat))) return rc;
     if ((rc = srx_ws_ensure(h, WS_SCALE, sizeof(float) * (size_t)n_frames, (void**)&scale))) return rc;
+    // (the replica records and, behind them, the counter that hands out the batches)
     const size_t rep_bytes = sizeof(double) * (size_t)kReplicas * M * rec_size;
-    if ((rc = srx_ws_ensure(h, WS_PARTIAL, rep_bytes, (void**)&replicas))) return rc;
-    SRX_HIP(hipMemsetAsync(replicas, 0, rep_bytes, st));
+    if ((rc = srx_ws_ensure(h, WS_PARTIAL, rep_bytes + 256, (void**)&replicas))) return rc;
+    SRX_HIP(hipMemsetAsync(replicas, 0, rep_bytes + 256, st));
+    unsigned long long* queue = (unsigned long long*)((char*)replicas + rep_bytes);
     // (a caller that gives no visiting order gets one that groups the utterances by
     // model: a batch of 16 is walked once per model present in it)
     int64_t E = U;                      // entries of the visiting order
@@ -770,7 +791,8 @@ int srx_fused_estep(srx_context* h, const void* X, const int64_t* off, int64_t U
 #define SRX_CASE(rq, hh, ntx)                                                                \
     if (RQ == rq && H == hh && NTX == ntx) {                                                  \
         rc = launch<rq, hh, ntx>(h, Xf, off, E, n_frames, utt_model, utt_order, md, tb,       \
-                                 batch_base, lat, scale, replicas, rec_size, st);             \
+                                 batch_base, lat, scale, replicas, rec_size, st, nullptr,     \
+                                 nullptr, queue);                                             \
     } else
     SRX_CASE(0, 1, 1) SRX_CASE(1, 0, 2) SRX_CASE(1, 1, 3) SRX_CASE(2, 0, 4) SRX_CASE(2, 1, 5)
     SRX_CASE(3, 0, 6)
