@@ -38,6 +38,8 @@
 #include "srx_internal.h"
 
 #include <math.h>
+
+#include <algorithm>
 #include <type_traits>
 
 namespace {
@@ -799,7 +801,9 @@ int srx_fused_estep(srx_context* h, const void* X, const int64_t* off, int64_t U
     { return SRX_EUNSUPPORTED; }
 #undef SRX_CASE
     if (rc) return rc;
-    hipLaunchKernelGGL(fused_finish_kernel, dim3(8), dim3(256), 0, st, (const double*)replicas, *md,
+    // (one thread per output sum: each adds its 64 replica values in order)
+    const unsigned g_fin = (unsigned)std::min<int64_t>(((int64_t)M * rec_size + 255) / 256, 4096);
+    hipLaunchKernelGGL(fused_finish_kernel, dim3(g_fin), dim3(256), 0, st, (const double*)replicas, *md,
                        rec_size, out_stats);
     SRX_HIP(hipGetLastError());
     return SRX_OK;
