@@ -834,6 +834,10 @@ int srx_fused_posteriors(srx_context* h, const void* X, const int64_t* off, int6
     if ((rc = srx_ws_ensure(h, WS_LATTICE, sizeof(float) * (size_t)n_frames * 16, (void**)&lat))) return rc;
     if ((rc = srx_ws_ensure(h, WS_SCALE, sizeof(float) * (size_t)n_frames, (void**)&scale))) return rc;
     SRX_HIP(hipMemsetAsync(out_lp, 0, sizeof(double) * (size_t)U, st));
+    // (the counter that hands out the batches)
+    unsigned long long* queue;
+    if ((rc = srx_ws_ensure(h, WS_PARTIAL, 256, (void**)&queue))) return rc;
+    SRX_HIP(hipMemsetAsync(queue, 0, 256, st));
     // a batch of 16 utterances is walked once per model present in it: group them
     const int64_t* order = nullptr;
     int64_t E = U;
@@ -849,7 +853,8 @@ int srx_fused_posteriors(srx_context* h, const void* X, const int64_t* off, int6
 #define SRX_CASE(rq, hh)                                                                         \
     if (RQ == rq && H == hh)                                                                     \
         return launch<rq, hh, 1, true>(h, Xf, off, E, n_frames, utt_model, order, md, tb,        \
-                                       batch_base, lat, scale, nullptr, 0, st, out_post, out_lp);
+                                       batch_base, lat, scale, nullptr, 0, st, out_post, out_lp, \
+                                       queue);
     SRX_CASE(0, 1) SRX_CASE(1, 0) SRX_CASE(1, 1) SRX_CASE(2, 0) SRX_CASE(2, 1) SRX_CASE(3, 0)
 #undef SRX_CASE
     return SRX_EUNSUPPORTED;
