@@ -10,7 +10,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 struct row_t { u32x4 a, b; u32x2 c; };
 
 // MODE bit 0: read X, bit 1: write lattice, bit 2: read lattice, bit 3: descending time
-template <int MODE, int NV = 0, int NM = 0, int EARLY = 0>
+template <int MODE, int NV = 0, int NM = 0, int EARLY = 0, int SAUX = 0, int LAUX = 0>
 __global__ __launch_bounds__(256, 2) void k(const float* X, int64_t n_batches, int T, int D, float* lat,
                                             float* scale, float* out) {
     const int lane = threadIdx.x & 63, g = lane >> 4, ul = lane & 15;
@@ -35,8 +35,8 @@ __global__ __launch_bounds__(256, 2) void k(const float* X, int64_t n_batches, i
                 r.c = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o - 16u * g + 128u + 8u * g, 0, 0);
             }
             if (MODE & 4) {
-                al = __builtin_amdgcn_raw_buffer_load_b128(rl, (unsigned)tt(t) * 1024u + ul * 64u + 16u * g, 0, 0);
-                sc = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)tt(t) * 64u + ul * 4u, 0, 0);
+                al = __builtin_amdgcn_raw_buffer_load_b128(rl, (unsigned)tt(t) * 1024u + ul * 64u + 16u * g, 0, LAUX);
+                sc = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)tt(t) * 64u + ul * 4u, 0, LAUX);
             }
         };
         row_t s[3] = {};
@@ -69,8 +69,8 @@ __global__ __launch_bounds__(256, 2) void k(const float* X, int64_t n_batches, i
                 }
                 if ((MODE & 2) && t0 + i < T) {
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{v, acc, v, acc}, rl,
-                                                           (unsigned)(t0 + i) * 1024u + ul * 64u + 16u * g, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(v, rs, g == 0 ? (unsigned)(t0 + i) * 64u + ul * 4u : 0xFFFFFF00u, 0, 0);
+                                                           (unsigned)(t0 + i) * 1024u + ul * 64u + 16u * g, 0, SAUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(v, rs, g == 0 ? (unsigned)(t0 + i) * 64u + ul * 4u : 0xFFFFFF00u, 0, SAUX);
                 }
                 if (!EARLY) load(t0 + i + 3, s[i], al[i], sc[i]);
             }
@@ -79,14 +79,14 @@ __global__ __launch_bounds__(256, 2) void k(const float* X, int64_t n_batches, i
     out[blockIdx.x * 256 + threadIdx.x] = (float)acc;
 }
 
-template <int MODE, int NV = 0, int NM = 0, int EARLY = 0>
+template <int MODE, int NV = 0, int NM = 0, int EARLY = 0, int SAUX = 0, int LAUX = 0>
 void run(const char* what, double bytes_per_frame, const float* X, int64_t U, int T, int D, float* lat, float* scale,
          float* out) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int i = 0; i < 5; ++i) k<MODE, NV, NM, EARLY><<<512, 256>>>(X, U / 16, T, D, lat, scale, out);
+    for (int i = 0; i < 5; ++i) k<MODE, NV, NM, EARLY, SAUX, LAUX><<<512, 256>>>(X, U / 16, T, D, lat, scale, out);
     (void)hipEventRecord(e0);
-    for (int i = 0; i < 10; ++i) k<MODE, NV, NM, EARLY><<<512, 256>>>(X, U / 16, T, D, lat, scale, out);
+    for (int i = 0; i < 10; ++i) k<MODE, NV, NM, EARLY, SAUX, LAUX><<<512, 256>>>(X, U / 16, T, D, lat, scale, out);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -114,6 +114,12 @@ int main() {
     run<1, 100, 24>("read X + 100 FMAs + 24 matrix", 156, X, U, T, D, lat, scale, out);
     run<5 | 8, 150, 48>("backward + 150 FMAs + 48 matrix", 224, X, U, T, D, lat, scale, out);
     run<0, 150, 48>("no memory: 150 FMAs + 48 matrix", 224, X, U, T, D, lat, scale, out);
+    // cache-policy bits of the lattice stores / loads (bit 0 sc0, bit 1 nt, bit 4 sc1)
+    run<3, 0, 0, 0, 2, 0>("forward, lattice stores nt", 224, X, U, T, D, lat, scale, out);
+    run<3, 0, 0, 0, 1, 0>("forward, lattice stores sc0", 224, X, U, T, D, lat, scale, out);
+    run<3, 0, 0, 0, 17, 0>("forward, lattice stores sc0 sc1", 224, X, U, T, D, lat, scale, out);
+    run<3, 0, 0, 0, 19, 0>("forward, lattice stores sc0 sc1 nt", 224, X, U, T, D, lat, scale, out);
+    run<5 | 8, 0, 0, 0, 0, 2>("backward, lattice loads nt", 224, X, U, T, D, lat, scale, out);
     for (int rep = 0; rep < 1; ++rep) {
         run<1>("read X", 156, X, U, T, D, lat, scale, out);
         run<2>("write lattice + scale", 68, X, U, T, D, lat, scale, out);
