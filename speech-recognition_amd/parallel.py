@@ -83,14 +83,13 @@ class BaumWelchTrainer:
             if um.size and (um.min() < 0 or um.max() >= bank.M):
                 raise ValueError("utt_model entry outside [0, n_models)")
             self.utt_model = ctx.tensor(um)
-            # Small float32 jobs: no visiting order -- the matrix-core E-step then groups the
-            # utterances by model itself (ascending inside a model, whole batches of 16 per
-            # model, so no batch is walked twice; rebuilt on every call, ~0.15 ms at 131,072
-            # utterances).  Large jobs, where the few batches that straddle two models do
-            # not matter, and the shape-generic float64 kernels (which keep a model's sums in
-            # registers while the model does not change) get the stable sort, made once here.
-            small = data.X.dtype == torch.float32 and data.U < 8192
-            self.utt_order = None if small else \
+            # float32: no visiting order -- the matrix-core E-step builds its own on the device
+            # (by model, then by length in descending buckets, whole batches of 16 per model, so
+            # no batch is walked twice and few matrix columns idle behind a long utterance;
+            # rebuilt on every call, about 30 us at 131,072 utterances).  The shape-generic
+            # float64 kernels, which keep a model's sums in registers while the model does not
+            # change, get a stable sort by model, made once here.
+            self.utt_order = None if data.X.dtype == torch.float32 else \
                 ctx.tensor(np.argsort(um, kind="stable").astype(np.int64))
         self.stats = torch.zeros((bank.M, bank.stats_size), dtype=torch.float64, device=ctx.device)
 
