@@ -331,6 +331,25 @@ def main():
                                "config": "state posteriors, one 8-state model per utterance (u mod 6), "
                                          "float32 (156 B in + 32 B out per frame)"}
         del plp, pgam, um
+        # the headline workload with ragged lengths (100 to 300 frames, mean 200), scored with the
+        # length order Ragged makes for such batches (utterances of similar length share a wave)
+        lens_r = np.random.default_rng(4).integers(100, 301, size=U)
+        n_r = int(lens_r.sum())
+        if n_r <= X.shape[0]:
+            data_r = sra.Ragged(ctx, X[:n_r], lens_r, dtype="float32")
+            sc_r = bank.score(data_r)
+            warm_gpu(lambda: bank.score(data_r, out=sc_r))
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                bank.score(data_r, out=sc_r)
+            barrier()
+            dtr = (time.perf_counter() - t0) / 10
+            extra["score_ragged"] = {"frames_per_s": n_r * world / dtr, "ms": dtr * 1e3,
+                                     "hbm_frac": n_r * N_FEAT * 4 / dtr / 1e9 / HBM_PEAK_GBS,
+                                     "config": f"{U} utterances of 100 to 300 frames ({n_r} frames), 6 x 8 states, "
+                                               "scored in descending length buckets (srx_forward_score_ordered)"}
+            del data_r, sc_r
         # the headline workload in the validation dtype: float64 features, every product of
         # the emission contraction on the f64 matrix instruction
         X64 = X.double()

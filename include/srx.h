@@ -189,6 +189,17 @@ int srx_emission_loglik(srx_handle_t h, const void* X, int dtype, int64_t n_fram
 int srx_forward_score(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
                       int64_t n_utts, int64_t n_frames, const srx_models_t* models,
                       double* out_scores, void* stream);
+/* The same with a visiting order (a permutation of 0 .. n_utts-1 on the device): the SRX_F32
+ * matrix-core kernel scores 16 consecutive entries of the order in one wave, step by step
+ * until the longest of them ends, so an order that puts utterances of similar length side by
+ * side (descending length buckets) keeps its matrix columns busy on ragged batches --
+ * the batched form of recognize's loop over files (HMM_final.py:134-165), where the files
+ * come in any order.  Results are those of srx_forward_score, out_scores[u, m] indexed by
+ * utterance, not by position.  The order is used while X is smaller than 4 GiB (one buffer
+ * descriptor must reach all of it) and ignored otherwise, for SRX_F64, and with NULL. */
+int srx_forward_score_ordered(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
+                              int64_t n_utts, int64_t n_frames, const int64_t* utt_order,
+                              const srx_models_t* models, double* out_scores, void* stream);
 /* Same contract, always through the shape-generic kernels (any S <= 64, any D);
  * srx_forward_score uses them only for shapes without a matrix-core kernel. */
 int srx_forward_score_generic(srx_handle_t h, const void* X, int dtype,

@@ -79,6 +79,7 @@ SIGNATURES = {
                                       _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "srx_emission_loglik": (C.c_int, [_vp, _vp, C.c_int, _i64, C.POINTER(Models), _vp, _vp]),
     "srx_forward_score": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, C.POINTER(Models), _vp, _vp]),
+    "srx_forward_score_ordered": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, _vp, C.POINTER(Models), _vp, _vp]),
     "srx_forward_score_generic": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, C.POINTER(Models), _vp, _vp]),
     "srx_forward_score_static": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, C.POINTER(Models), _vp, _vp]),
     "srx_static_scratch_bytes": (_i64, []),

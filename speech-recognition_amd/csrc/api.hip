@@ -261,6 +261,24 @@ int srx_forward_score(srx_handle_t h, const void* X, int dtype, const int64_t* u
                              (hipStream_t)stream);
 }
 
+int srx_forward_score_ordered(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
+                              int64_t n_utts, int64_t n_frames, const int64_t* utt_order,
+                              const srx_models_t* models, double* out_scores, void* stream) {
+    if (utt_order == nullptr || dtype != SRX_F32)
+        return srx_forward_score(h, X, dtype, utt_offsets, n_utts, n_frames, models, out_scores, stream);
+    int rc = check_common(h, X, dtype, n_utts, n_frames, utt_offsets, "srx_forward_score_ordered");
+    if (rc) return rc;
+    if ((rc = check_models(models, "srx_forward_score_ordered"))) return rc;
+    if (n_utts == 0) return SRX_OK;
+    SRX_REQUIRE(out_scores != nullptr, "srx_forward_score_ordered: NULL out_scores");
+    SRX_HIP(hipSetDevice(h->device));
+    rc = srx_mfma_score_tables(h, X, utt_offsets, n_utts, n_frames, models, out_scores, nullptr, 0,
+                               (hipStream_t)stream, utt_order);
+    if (rc != SRX_EUNSUPPORTED) return rc;
+    return srx_generic_score(h, X, dtype, utt_offsets, n_utts, n_frames, models, out_scores,
+                             (hipStream_t)stream);
+}
+
 int64_t srx_static_scratch_bytes(void) { return (int64_t)kStaticScratchBytes; }
 
 int srx_forward_score_static(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,

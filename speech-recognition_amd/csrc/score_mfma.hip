@@ -541,7 +541,7 @@ int srx_mfma_emission(srx_context* h, const void* X, int64_t n_frames, const srx
     float* cst = (float*)(base + n_wp);
     float* A = cst + n_c;
     float* pi = A + (size_t)M * S * S;
-    tb.Wp = base; tb.cst = cst; tb.A = A; tb.pi = pi;
+    tb.Wp = base; tb.cst = cst; tb.A = A; tb.pi = pi; tb.order = nullptr;
     // rows of the table = columns of the output: "padded states per model" = S
     hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, S, NT, RQ, 0, base, cst, A, pi);
     const int NTC = NT >= 3 ? 3 : NT;
@@ -580,7 +580,7 @@ int srx_mfma_emission_utt(srx_context* h, const void* X, const int64_t* off, int
     float* cst = (float*)(base + n_wp);
     float* A = cst + n_c;
     float* pi = A + (size_t)M * S * S;
-    tb.Wp = base; tb.cst = cst; tb.A = A; tb.pi = pi;
+    tb.Wp = base; tb.cst = cst; tb.A = A; tb.pi = pi; tb.order = nullptr;
     // one 16-row tile per model
     hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, 16, NT, RQ, 0, base, cst, A, pi);
     int64_t gx = (U + 3) / 4;
@@ -704,13 +704,16 @@ __global__ __launch_bounds__(64) void score_far_kernel(const float* __restrict__
 
 int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
                    const srx_models_t* md, double* out, hipStream_t st) {
-    return srx_mfma_score_tables(h, X, off, U, n_frames, md, out, nullptr, 0, st);
+    return srx_mfma_score_tables(h, X, off, U, n_frames, md, out, nullptr, 0, st, nullptr);
 }
 
 int srx_mfma_score_tables(srx_context* h, const void* X, const int64_t* off, int64_t U,
                           int64_t n_frames, const srx_models_t* md, double* out, void* tables,
-                          size_t tables_bytes, hipStream_t st) {
+                          size_t tables_bytes, hipStream_t st, const int64_t* order) {
     const int M = md->n_models, S = md->n_states, D = md->n_features;
+    // a visiting order puts utterances from anywhere in X into one batch: only the kernel with
+    // one descriptor over all of X can follow it, and only while X is within its reach
+    if (order && n_frames * (int64_t)D * 4 >= 0xFFFFFF00ll) order = nullptr;
     if (S > 16 || D > 48 || n_frames <= 0) return SRX_EUNSUPPORTED;
     if (tables && h->exact_f32) return SRX_EUNSUPPORTED;
     if (h->exact_f32 && (D > 40 || S > 8)) return SRX_EUNSUPPORTED;
@@ -751,10 +754,10 @@ int srx_mfma_score_tables(srx_context* h, const void* X, const int64_t* off, int
         const float* Xf = (const float*)X;
         int rc;
         if (SP == 16)
-            rc = srx_split_score_sp16(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st);
+            rc = srx_split_score_sp16(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st, order);
         else
-            rc = SP == 8 ? srx_split_score_sp8(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st)
-                         : srx_split_score_sp4(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st);
+            rc = SP == 8 ? srx_split_score_sp8(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st, order)
+                         : srx_split_score_sp4(Xf, off, U, n_frames, M, S, D, NTC, chunks, RQ, H, base, cst, A, pi, out, st, order);
         if (rc) return rc;
         // only a buffer of 4 GiB or more can hold a batch the split kernel has skipped
         if (n_frames * (int64_t)D * 4 >= 0xFFFFFF00ll) {

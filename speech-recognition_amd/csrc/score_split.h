@@ -80,6 +80,7 @@ struct SplitTables {
     const float* cst;     // [NT*16]
     const float* A;       // [M][S][S]
     const float* pi;      // [M][S]
+    const int64_t* order; // scoring: visiting order of the utterances (a permutation), or NULL
 };
 
 __device__ __host__ inline unsigned bf16_rne(float f) {
@@ -152,8 +153,11 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
     if (group * 16 >= U) return;
     // banks of more than NT tiles: blockIdx.y takes tiles [tile0, tile0 + NT)
     const int tile0 = blockIdx.y * NT;
-    const int64_t u = group * 16 + ul;
-    const bool valid = u < U;
+    // (with a visiting order -- the caller's way of putting utterances of similar length into one
+    // batch -- lane ul takes entry group*16 + ul of it; the host passes one only when all of X
+    // is within a descriptor's reach, since the utterances of a batch then lie anywhere)
+    const bool valid = group * 16 + ul < U;
+    const int64_t u = valid ? (tb.order ? tb.order[group * 16 + ul] : group * 16 + ul) : 0;
     const int64_t uc = valid ? u : U - 1;
     const int64_t f0 = off[uc];
     const int T = valid ? (int)(off[uc + 1] - f0) : 0;
@@ -163,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
 
     // ---- per-wave buffer descriptor over [first row of the batch, end of X)
     const int64_t u_last = group * 16 + 15 < U - 1 ? group * 16 + 15 : U - 1;
-    const int64_t fbase = off[group * 16];
-    const int64_t span = (off[u_last + 1] - fbase) * D * 4;           // bytes, uniform
+    const int64_t fbase = tb.order ? 0 : off[group * 16];
+    const int64_t span = tb.order ? 0 : (off[u_last + 1] - fbase) * D * 4;           // bytes, uniform
     const int64_t rest = (n_frames - fbase) * (int64_t)D * 4;
     const unsigned nrec = (unsigned)(rest < 0xFFFFFF00ll ? rest : 0xFFFFFF00ll);
     // One descriptor reaches 4 GiB.  A batch whose frames span more is left to
@@ -490,10 +494,10 @@ void launch_split(const float* X, const int64_t* off, int64_t U, int64_t n_frame
 // hold chunks * NT tiles).
 int srx_split_score_sp8(const float* X, const int64_t* off, int64_t U, int64_t n_frames, int M,
                         int S, int D, int NT, int chunks, int RQ, int H, const unsigned* Wp, const float* cst,
-                        const float* A, const float* pi, double* out, hipStream_t st);
+                        const float* A, const float* pi, double* out, hipStream_t st, const int64_t* order);
 int srx_split_score_sp4(const float* X, const int64_t* off, int64_t U, int64_t n_frames, int M,
                         int S, int D, int NT, int chunks, int RQ, int H, const unsigned* Wp, const float* cst,
-                        const float* A, const float* pi, double* out, hipStream_t st);
+                        const float* A, const float* pi, double* out, hipStream_t st, const int64_t* order);
 int srx_split_score_sp16(const float* X, const int64_t* off, int64_t U, int64_t n_frames, int M,
                          int S, int D, int NT, int chunks, int RQ, int H, const unsigned* Wp, const float* cst,
-                         const float* A, const float* pi, double* out, hipStream_t st);
+                         const float* A, const float* pi, double* out, hipStream_t st, const int64_t* order);

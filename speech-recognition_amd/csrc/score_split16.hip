@@ -3,9 +3,9 @@
 
 int srx_split_score_sp16(const float* X, const int64_t* off, int64_t U, int64_t n_frames, int M,
                          int S, int D, int NT, int chunks, int RQ, int H, const unsigned* Wp, const float* cst,
-                        const float* A, const float* pi, double* out, hipStream_t st) {
+                        const float* A, const float* pi, double* out, hipStream_t st, const int64_t* order) {
     SplitTables tb;
-    tb.Wp = Wp; tb.cst = cst; tb.A = A; tb.pi = pi;
+    tb.Wp = Wp; tb.cst = cst; tb.A = A; tb.pi = pi; tb.order = order;
 #define SRX_CASE(nt, rq, hh)                                                       \
     if (NT == nt && RQ == rq && H == hh) {                                         \
         launch_split<16, nt, rq, hh>(X, off, U, n_frames, M, S, D, chunks, tb, out, st); \

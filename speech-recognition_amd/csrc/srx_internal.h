@@ -142,7 +142,7 @@ int srx_mfma_score(srx_context* h, const void* X, const int64_t* off, int64_t U,
 // allocated.  Only the split-bf16 kernels; SRX_EINVAL when the tables do not fit.
 int srx_mfma_score_tables(srx_context* h, const void* X, const int64_t* off, int64_t U,
                           int64_t n_frames, const srx_models_t* models, double* out, void* tables,
-                          size_t tables_bytes, hipStream_t st);
+                          size_t tables_bytes, hipStream_t st, const int64_t* order = nullptr);
 
 // Implemented in score_f64.hip: float64 scoring on the f64 matrix instruction (<= 8 states,
 // <= 48 features), else SRX_EUNSUPPORTED.

@@ -147,6 +147,24 @@ class Ragged:
             self.offsets_host = off
             self.offsets = ctx.tensor(off)
             self.U = len(off) - 1
+        self._length_order = False           # not computed yet
+
+    def length_order(self):
+        """Visiting order for the batched kernels: utterances by length in 32 descending
+        buckets (stable inside a bucket, so neighbours in memory stay neighbours), as an int64
+        device tensor; None when all utterances have the same length or there are too few to
+        matter.  Computed once per object."""
+        if self._length_order is False:
+            if self.offsets_host is not None:
+                lengths = np.diff(np.asarray(self.offsets_host, dtype=np.int64))
+            else:
+                lengths = (self.offsets[1:] - self.offsets[:-1]).cpu().numpy()
+            order = None
+            if self.U > 32 and lengths.size and lengths.min() != lengths.max():
+                bucket = lengths * 32 // (int(lengths.max()) + 1)
+                order = self.ctx.tensor(np.argsort(-bucket, kind="stable").astype(np.int64))
+            self._length_order = order
+        return self._length_order
 
 
 class HMMBank:
@@ -236,6 +254,13 @@ class HMMBank:
         self._check(data)
         if out is None:
             out = torch.empty((data.U, self.M), dtype=torch.float64, device=self.ctx.device)
+        # ragged float32 batches: utterances of similar length share a wave
+        order = data.length_order() if not generic and data.X.dtype == torch.float32 else None
+        if order is not None:
+            check(lib.srx_forward_score_ordered(self.ctx.handle, ptr(data.X), data.code, ptr(data.offsets),
+                                                data.U, data.n_frames, ptr(order), C.byref(self._struct),
+                                                ptr(out), self.ctx.stream_ptr()), "srx_forward_score_ordered")
+            return out
         fn = lib.srx_forward_score_generic if generic else lib.srx_forward_score
         check(fn(self.ctx.handle, ptr(data.X), data.code, ptr(data.offsets), data.U, data.n_frames,
                  C.byref(self._struct), ptr(out), self.ctx.stream_ptr()), "srx_forward_score")

@@ -831,6 +831,38 @@ def test_small_job_estep_paths_agree_with_oracle(sra, ctx, M, S, D):
         assert np.abs(res[dtype, "lane"] - res[dtype, "fused"]).max() <= 2 * tol * scale
 
 
+def test_scoring_with_a_length_order_is_bit_identical(sra, ctx):
+    """Ragged float32 batches are scored through srx_forward_score_ordered (utterances of
+    similar length share a wave): bit for bit the scores of srx_forward_score, which takes
+    them in memory order, and within the float32 bound of the oracle's."""
+    import ctypes as C
+    import torch
+    from speech_recognition_amd import _lib
+    rng = np.random.default_rng(21)
+    M, S, D, U = 6, 8, 39, 333
+    prms = [ho.random_params(rng, S, D) for _ in range(M)]
+    lengths = rng.integers(0, 120, size=U)
+    lengths[[0, 17, 332]] = [0, 1, 119]
+    X = rng.standard_normal((int(lengths.sum()), D))
+    bank = _bank(sra, ctx, prms)
+    data = sra.Ragged(ctx, X, lengths, dtype="float32")
+    order = data.length_order()
+    assert order is not None and sorted(order.cpu().tolist()) == list(range(U))
+    got = bank.score(data)
+    plain = torch.empty_like(got)
+    _lib.check(_lib.lib.srx_forward_score(ctx.handle, data.X.data_ptr(), data.code, data.offsets.data_ptr(),
+                                          data.U, data.n_frames, C.byref(bank._struct), plain.data_ptr(),
+                                          ctx.stream_ptr()))
+    assert torch.equal(got, plain)
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    for u in (1, 17, 100, 332):
+        for m in (0, M - 1):
+            want = float(np.sum(ho.score(prms[m], X[off[u]:off[u + 1]], loops=False)))
+            assert abs(float(got[u, m]) - want) <= 2e-5 * abs(want)
+    # equal lengths: no order is made
+    assert sra.Ragged(ctx, X[:4000], [40] * 100, dtype="float32").length_order() is None
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_estep_without_utterances_or_frames(sra, ctx, dtype):
     """No utterance at all, and utterances that are all empty: the statistics are zeros (the
