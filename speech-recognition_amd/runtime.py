@@ -155,12 +155,14 @@ class Ragged:
         device tensor; None when all utterances have the same length or there are too few to
         matter.  Computed once per object."""
         if self._length_order is False:
-            if self.offsets_host is not None:
+            order = None
+            if self.U <= 32:                     # two batches at most: nothing to gain
+                lengths = np.zeros(0, dtype=np.int64)
+            elif self.offsets_host is not None:
                 lengths = np.diff(np.asarray(self.offsets_host, dtype=np.int64))
             else:
                 lengths = (self.offsets[1:] - self.offsets[:-1]).cpu().numpy()
-            order = None
-            if self.U > 32 and lengths.size and lengths.min() != lengths.max():
+            if lengths.size and lengths.min() != lengths.max():
                 bucket = lengths * 32 // (int(lengths.max()) + 1)
                 order = self.ctx.tensor(np.argsort(-bucket, kind="stable").astype(np.int64))
             self._length_order = order
