@@ -1,5 +1,5 @@
 """Random model / batch shapes through the float32 fast paths against the numpy oracle:
-python tools/fuzz_shapes.py [n_cases] [seed] [float32|float64].  Prints the first failure
+python tools/fuzz_shapes.py [n_cases] [seed] [float32|float64] [max utterances].  Prints the first failure
 and exits 1.  float64 runs the f64 matrix-core scoring kernel (up to 16 states, 48 features) and the
 shape-generic kernels (states up to 40) with tolerances a million times tighter."""
 import os, sys, numpy as np, torch
@@ -10,6 +10,7 @@ from oracle import hmm_oracle as ho
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dtype = sys.argv[3] if len(sys.argv) > 3 else "float32"
+max_u = int(sys.argv[4]) if len(sys.argv) > 4 else 40      # more than 32 utterances: visiting orders are made
 tight = 1e-6 if dtype == "float64" else 1.0
 ctx = sra.Context.default(0)
 rng = np.random.default_rng(seed)
@@ -18,7 +19,7 @@ for case in range(n_cases):
     M = int(rng.integers(1, 9)) if rng.random() < 0.8 else int(rng.integers(9, 40))
     S = int(rng.integers(1, 17 if dtype == "float32" else 41))
     D = int(rng.integers(1, 49 if dtype == "float32" else 70))
-    U = int(rng.integers(1, 40))
+    U = int(rng.integers(1, max_u))
     lengths = rng.integers(0, 60, size=U)
     lengths[rng.integers(0, U)] = int(rng.integers(1, 300))
     prms = [ho.random_params(rng, S, D) for _ in range(M)]
