@@ -96,6 +96,30 @@ def cpu_baseline(sample_utts, seed=1234):
                 dtp = time.perf_counter() - t3
             res["compiled_c_pool_frames_per_s"] = workers * per * T_FRAMES / dtp
             res["compiled_c_pool_workers"] = workers
+    # the loop-faithful Python code itself on the box's CPU share: one process per core (child
+    # processes that never touch the GPU), each scoring its own slice of utterances
+    import subprocess
+    workers = min(16, os.cpu_count() or 1)
+    per = max(sample_utts // 8, 8)
+    code = ("import sys, time, numpy as np; sys.path.insert(0, %r); from oracle import hmm_oracle as ho\n"
+            "r = np.random.default_rng(7); M, S, D, T, n = %d, %d, %d, %d, %d\n"
+            "sp, A = r.dirichlet(np.ones(S), size=M), r.dirichlet(np.ones(S), size=(M, S))\n"
+            "mu, cv = r.standard_normal((M, S, D)), r.uniform(0.5, 1.5, (M, S, D))\n"
+            "X = np.random.default_rng(int(sys.argv[1])).standard_normal((n * T, D))\n"
+            "t0 = time.perf_counter()\n"
+            "for m in range(M): ho.score(ho.Params(sp[m], A[m], mu[m], cv[m]), X, [T] * n, loops=True)\n"
+            "print(time.perf_counter() - t0)\n") % (ROOT, N_MODELS, N_STATES, N_FEAT, T_FRAMES, per)
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    t4 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(w)], stdout=subprocess.PIPE, env=env)
+             for w in range(workers)]
+    ok = all(p.wait() == 0 for p in procs)
+    dtq = time.perf_counter() - t4
+    if ok:
+        inner = max(float(p.stdout.read().decode().strip() or 0.0) for p in procs)
+        res["python_loops_pool_frames_per_s"] = workers * per * T_FRAMES / max(inner, 1e-9)
+        res["python_loops_pool_workers"] = workers
+        res["python_loops_pool_wall_s"] = dtq
     return res
 
 
