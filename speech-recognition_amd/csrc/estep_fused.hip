@@ -501,44 +501,65 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                 }
                 bb = live ? b * beta : f32x4{0.f, 0.f, 0.f, 0.f};
             };
-            for (int t0 = Tmax - 1; t0 >= 0; t0 -= 2) {
+            // Sums so far -> this wave's global float64 record, accumulators back to zero.
+            // G and O are in accumulator layout: lane (g, ul) holds rows 4g+reg, column ul.
+            // (Called at the end of a batch, and every kFlushSteps steps inside one: the float32
+            // accumulators then never hold more than 16 * kFlushSteps terms, however long the
+            // utterances are.)
+            auto flush_sums = [&]() {
+                double* dst = my_rep + (size_t)m_cur * rec_size;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int t = t0 - i;             // t = -1: a dead step, writes zero tiles
-                    if constexpr (!POST) consume(tiles + TILE * (i ^ 1));
-                    produce(t, tiles + TILE * i, xq[i], alq[i], ciq[i]);
-                    loadb(t - 2, xq[i], alq[i], ciq[i]);
-                    if constexpr (!POST) wave_sync();
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int si = sigma(4 * g + reg), sj = sigma(ul);
+                    if (si < S && sj < S) unsafeAtomicAdd(dst + L.trans + si * S + sj, (double)G[reg]);
+                    G[reg] = 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < NTX; ++nt) {
+                        const int c = 16 * nt + ul;
+                        const int d = c < DP ? c : c - DP;
+                        if (si < S && d < D)
+                            unsafeAtomicAdd(dst + (c < DP ? L.obs : L.obs2) + si * D + d, (double)O[nt][reg]);
+                        O[nt][reg] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float ps = sum_u(post[reg]);
+                    const int s = 4 * reg + g;
+                    if (ul == 0 && s < S) unsafeAtomicAdd(dst + L.post + s, (double)ps);
+                    post[reg] = 0.f;
+                }
+            };
+            // (the walk is cut into runs of kFlushSteps steps with one flush after each)
+            constexpr int kFlushSteps = 512;
+            for (int hi = Tmax - 1; hi >= 0; hi -= kFlushSteps) {
+                const int lo = hi >= kFlushSteps ? hi - kFlushSteps + 1 : 0;
+                for (int t0 = hi; t0 >= lo; t0 -= 2) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int t = t0 - i;             // t = -1: a dead step, writes zero tiles
+                        if constexpr (!POST) consume(tiles + TILE * (i ^ 1));
+                        produce(t, tiles + TILE * i, xq[i], alq[i], ciq[i]);
+                        loadb(t - 2, xq[i], alq[i], ciq[i]);
+                        if constexpr (!POST) wave_sync();
+                    }
+                }
+                if constexpr (!POST) {
+                    if (lo == 0) consume(tiles + TILE);   // the last step produced
+                    flush_sums();
                 }
             }
-            if constexpr (!POST) consume(tiles + TILE);   // the last step produced
 
             if constexpr (POST) {
                 if (active && g == 0) post_lp[u] = span_ok ? lp * kLn2 : __builtin_nan("");
             } else {
-            // ---------------- batch sums -> this wave's global float64 record
-            // G and O are in accumulator layout: lane (g, ul) holds rows 4g+reg, column ul.
+            // ---------------- what is left of the batch sums
             double* dst = my_rep + (size_t)m_cur * rec_size;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int si = sigma(4 * g + reg), sj = sigma(ul);
-                if (si < S && sj < S) unsafeAtomicAdd(dst + L.trans + si * S + sj, (double)G[reg]);
-#pragma unroll
-                for (int nt = 0; nt < NTX; ++nt) {
-                    const int c = 16 * nt + ul;
-                    const int d = c < DP ? c : c - DP;
-                    if (si < S && d < D)
-                        unsafeAtomicAdd(dst + (c < DP ? L.obs : L.obs2) + si * D + d, (double)O[nt][reg]);
-                }
-            }
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const float ps = sum_u(post[reg]), ss = sum_u(start[reg]);
+                const float ss = sum_u(start[reg]);
                 const int s = 4 * reg + g;
-                if (ul == 0 && s < S) {
-                    unsafeAtomicAdd(dst + L.post + s, (double)ps);
-                    unsafeAtomicAdd(dst + L.start + s, (double)ss);
-                }
+                if (ul == 0 && s < S) unsafeAtomicAdd(dst + L.start + s, (double)ss);
             }
             {
                 double lps = span_ok ? lp : __builtin_nan("");

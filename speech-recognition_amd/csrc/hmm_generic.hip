@@ -930,6 +930,19 @@ __global__ __launch_bounds__(64) void fb_lane_kernel(
         lr = lr_n;
         ar = ar_n;
         c4 = c4_n;
+        if constexpr (STATS) {
+            // (the float32 xi sums never hold more than 2048 frames)
+            if ((t & 2047) < 4) {
+                double* a = acc_lds + (size_t)m * P;
+#pragma unroll
+                for (int i = 0; i < S; ++i)
+#pragma unroll
+                    for (int j = 0; j < S; ++j) {
+                        atomicAdd(&a[i * S + j], (double)xi[i][j]);
+                        xi[i][j] = 0.f;
+                    }
+            }
+        }
     }
     for (; t >= 0; --t) {
         float row[S], ar[S], o[S];

@@ -863,6 +863,35 @@ def test_scoring_with_a_length_order_is_bit_identical(sra, ctx):
     assert sra.Ragged(ctx, X[:4000], [40] * 100, dtype="float32").length_order() is None
 
 
+@pytest.mark.parametrize("S,path", [(3, "lane"), (3, "fused"), (16, "fused")])
+def test_estep_long_utterances(sra, ctx, S, path):
+    """Utterances of thousands of frames: the float32 accumulators of both E-step kernels are
+    folded into float64 every few hundred frames, so the statistics keep the 2e-5 of short
+    utterances."""
+    rng = np.random.default_rng(300 + S)
+    D, M = 13, 2
+    prms = [ho.random_params(rng, S, D) for _ in range(M)]
+    lengths = np.array([5000, 1, 2300, 700, 4100, 2049, 513, 64, 3000, 1025, 2048, 511, 512, 4096, 333, 1500,
+                        2600, 40], dtype=np.int64)
+    um = (np.arange(len(lengths)) % M).astype(np.int32)
+    X = rng.standard_normal((int(lengths.sum()), D))
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    bank = _bank(sra, ctx, prms)
+    ctx.set_estep_path(path)
+    try:
+        got = bank.unpack_stats(bank.estep(sra.Ragged(ctx, X, lengths, dtype="float32"), ctx.tensor(um)))
+    finally:
+        ctx.set_estep_path("auto")
+    for m in range(M):
+        sel = [u for u in range(len(lengths)) if um[u] == m]
+        Xm = np.vstack([X[off[u]:off[u + 1]] for u in sel])
+        st, lps = ho.estep(prms[m], Xm, [int(lengths[u]) for u in sel], loops=False)
+        assert got[m]["nobs"] == len(sel)
+        assert abs(got[m]["logprob"] - float(np.sum(lps))) <= 1e-5 * abs(float(np.sum(lps)))
+        for k in ("start", "trans", "post", "obs", "obs**2"):
+            np.testing.assert_allclose(got[m][k], st[k], rtol=2e-5, atol=2e-5 * max(1.0, np.abs(st[k]).max()))
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_estep_without_utterances_or_frames(sra, ctx, dtype):
     """No utterance at all, and utterances that are all empty: the statistics are zeros (the
