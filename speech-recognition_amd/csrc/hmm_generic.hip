@@ -601,6 +601,7 @@ __global__ void viterbi_chain_kernel(const T* __restrict__ loglik,
         const T* ll = loglik + f0 * S + j;
         uint8_t* b = bp + f0 * S + j;
         T v = j < S ? tb.logpi[m * S + j] + ll[0] : neg_inf<T>();
+        double shift = 0.0;
         for (int t = 1; t < T_len; ++t) {
             T best = neg_inf<T>();
             int arg = 0;
@@ -616,6 +617,16 @@ __global__ void viterbi_chain_kernel(const T* __restrict__ loglik,
                 v = best + ll[(int64_t)t * S];
                 b[(int64_t)t * S] = (uint8_t)arg;
             }
+            if constexpr (std::is_same<T, float>::value) {
+                // (float32: delta kept relative to its largest entry, see viterbi_lane_kernel)
+                if ((t & 7) == 0) {
+                    const T top = sub_max<T, SP>(v);
+                    if (top > neg_inf<T>()) {
+                        shift += (double)top;
+                        v -= top;
+                    }
+                }
+            }
         }
         T best = neg_inf<T>();
         int arg = 0;
@@ -628,7 +639,7 @@ __global__ void viterbi_chain_kernel(const T* __restrict__ loglik,
             }
         }
         if (j == 0) {
-            out_lp[u] = (double)best;
+            out_lp[u] = shift + (double)best;
             int s = arg;
             path[f0 + T_len - 1] = s;
             const uint8_t* bq = bp + f0 * S;
@@ -694,6 +705,7 @@ __global__ __launch_bounds__(64) void viterbi_lane_kernel(
     };
     // frames 1 .. T-1 in pieces of four, the next piece requested before this one is used
     int t = 1;
+    double shift = 0.0;                  // what has been taken off delta so far
     Rows4 cur, nxt;
     if (t + 4 <= T_len) cur = *(const Rows4*)(ll + (size_t)t * S);
     for (; t + 4 <= T_len; t += 4) {
@@ -703,6 +715,17 @@ __global__ __launch_bounds__(64) void viterbi_lane_kernel(
         for (int k = 0; k < 4; ++k) w.v[k] = step(cur.v + k * S);
         *(Words4*)(bw + t) = w;
         cur = nxt;
+        // delta is kept relative to its largest entry (the path does not change): a float32
+        // lattice that grows by ~50 per frame would compare candidates with an ulp of 1e-3
+        // after 200 frames and of 0.03 after 5000
+        float top = d[0];
+#pragma unroll
+        for (int j = 1; j < S; ++j) top = fmaxf(top, d[j]);
+        if (top > neg_inf<float>()) {
+            shift += (double)top;
+#pragma unroll
+            for (int j = 0; j < S; ++j) d[j] -= top;
+        }
     }
     for (; t < T_len; ++t) {
         float row[S];
@@ -718,7 +741,7 @@ __global__ __launch_bounds__(64) void viterbi_lane_kernel(
             best = d[i];
             s = i;
         }
-    out_lp[u] = (double)best;
+    out_lp[u] = shift + (double)best;
     // backtrace: path[t] = back-pointer of frame t+1 at the state of frame t+1
     int32_t* p = path + f0;
     p[T_len - 1] = s;

@@ -892,6 +892,31 @@ def test_estep_long_utterances(sra, ctx, S, path):
             np.testing.assert_allclose(got[m][k], st[k], rtol=2e-5, atol=2e-5 * max(1.0, np.abs(st[k]).max()))
 
 
+@pytest.mark.parametrize("S", [5, 12])
+def test_viterbi_float32_long_utterances(sra, ctx, S):
+    """Utterances of thousands of frames through the float32 Viterbi kernels (one lane per
+    utterance up to 8 states, the sub-wave chain above): the lattice is kept relative to its
+    maximum, so the float32 paths part from the float64 ones only at near-ties (1e-6 of the
+    score here) and the log-probability keeps 1e-6 relative, whatever the length."""
+    from conftest import assert_ties_only
+    rng = np.random.default_rng(40 + S)
+    D = 13
+    prm = ho.random_params(rng, S, D)
+    lengths = np.array([6000, 1, 2500, 17, 4097], dtype=np.int64)
+    X = rng.standard_normal((int(lengths.sum()), D)).astype(np.float32).astype(np.float64)
+    bank = _bank(sra, ctx, [prm])
+    lp64, path64 = bank.viterbi(sra.Ragged(ctx, X, lengths, dtype="float64"))
+    lp32, path32 = bank.viterbi(sra.Ragged(ctx, X, lengths, dtype="float32"))
+    lp64, path64, lp32, path32 = (v.cpu().numpy() for v in (lp64, path64, lp32, path32))
+    want_lp, want_path = ho.viterbi(prm, X[:6000])
+    np.testing.assert_array_equal(path64[:6000], want_path)
+    log_B = ho.log_density_diag(X, prm.means, prm.covars)
+    n_diff, gap, short = assert_ties_only(prm.pi, prm.A, log_B, lengths, path32, path64, lp64, eps=1e-6)
+    print(f"viterbi float32, {S} states, {int(lengths.sum())} frames: {n_diff} differ, largest tie gap {gap:.2e}")
+    assert n_diff <= 20
+    assert np.abs(lp32 - lp64).max() <= 1e-6 * np.abs(lp64).max()
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_estep_without_utterances_or_frames(sra, ctx, dtype):
     """No utterance at all, and utterances that are all empty: the statistics are zeros (the
