@@ -695,13 +695,21 @@ __device__ __forceinline__ int order_key(const int32_t* utt_model, const int64_t
 }
 __global__ __launch_bounds__(256) void order_tmax_kernel(const int64_t* __restrict__ off, int64_t U,
                                                          unsigned* __restrict__ tmax) {
+    __shared__ unsigned part[4];
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t T = u < U ? off[u + 1] - off[u] : 0;
     if (T > 0x7FFFFFFFll) T = 0x7FFFFFFFll;
     unsigned v = (unsigned)T;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
-    if ((threadIdx.x & 63) == 0 && v) atomicMax(tmax, v);      // (a maximum does not depend on the order)
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v = max(max(part[0], part[1]), max(part[2], part[3]));
+        // one atomic per workgroup, and none when the value seen is already as large (a stale
+        // read only costs an atomic; a maximum does not depend on the order)
+        if (v > *(volatile unsigned*)tmax) atomicMax(tmax, v);
+    }
 }
 __global__ __launch_bounds__(256) void order_hist_kernel(const int32_t* __restrict__ utt_model,
                                                          const int64_t* __restrict__ off, int64_t U, int K,
