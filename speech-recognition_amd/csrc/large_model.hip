@@ -331,9 +331,18 @@ struct Neg<double> {
 template <typename T, int UB>
 __global__ __launch_bounds__(1024) void viterbi_dense_kernel(
     const T* __restrict__ ll, const int64_t* __restrict__ off, int64_t U, int S,
-    const T* __restrict__ logpi, const T* __restrict__ logA, T* __restrict__ delta_out) {
+    const T* __restrict__ logpi, const T* __restrict__ logA, T* __restrict__ delta_out,
+    double* __restrict__ shift_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vraw[];
     T* dl = (T*)vraw;                        // [2][S][UB]: delta of the previous / this step
+    // Every kRenorm steps delta of an utterance is made relative to its largest entry (what was
+    // taken off goes to shift_out[u] for the log-probability): a float32 lattice that grows by
+    // tens per frame would otherwise lose the resolution to tell candidates apart.  The stored
+    // rows stay consistent: the backtrace only compares entries of one row.
+    constexpr int kRenorm = 64;
+    __shared__ T red[UB];
+    __shared__ double shift_acc[UB];
+    if (threadIdx.x < UB) shift_acc[threadIdx.x] = 0.0;
     const int j = threadIdx.x;
     const int64_t u0 = (int64_t)blockIdx.x * UB;
     int64_t f0[UB];
@@ -386,13 +395,38 @@ __global__ __launch_bounds__(1024) void viterbi_dense_kernel(
             }
         }
         __syncthreads();
+        if (sizeof(T) == 4 && t % kRenorm == 0) {      // (float64 has the headroom: left as it is)
+            // largest entry per utterance, found by the first wave alone
+            if (threadIdx.x < 64) {
+                for (int b = 0; b < UB; ++b) {
+                    T v = Neg<T>::inf();
+                    for (int i = threadIdx.x; i < S; i += 64) v = fmax(v, cur[(size_t)i * UB + b]);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+                    // (an utterance at or past its last frame keeps what it has: its last row is stored)
+                    const bool on = t < Tl[b] - 1 && v > Neg<T>::inf();
+                    if (threadIdx.x == 0) {
+                        red[b] = on ? v : (T)0;
+                        if (on) shift_acc[b] += (double)v;
+                    }
+                }
+            }
+            __syncthreads();
+            if (own) {
+#pragma unroll
+                for (int b = 0; b < UB; ++b) cur[(size_t)j * UB + b] -= red[b];
+            }
+            __syncthreads();
+        }
     }
+    if (threadIdx.x < UB && u0 + threadIdx.x < U) shift_out[u0 + threadIdx.x] = shift_acc[threadIdx.x];
 }
 
 // One wave per utterance: final arg max, then s_{t-1} = argmax_i delta_{t-1}(i) + log A(i, s_t)
 template <typename T>
 __global__ void viterbi_backtrace_kernel(const T* __restrict__ delta, const int64_t* __restrict__ off,
                                          int64_t U, int S, const T* __restrict__ logAT,
+                                         const double* __restrict__ shift,
                                          int32_t* __restrict__ path, double* __restrict__ out_lp) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -429,7 +463,7 @@ __global__ void viterbi_backtrace_kernel(const T* __restrict__ delta, const int6
         T v;
         int s = argmax(delta + (f0 + Tl - 1) * S, nullptr, &v);
         if (lane == 0) {
-            out_lp[u] = (double)v;
+            out_lp[u] = shift[u] + (double)v;
             path[f0 + Tl - 1] = s;
         }
         for (int t = Tl - 2; t >= 0; --t) {
@@ -449,6 +483,9 @@ int viterbi_dense_t(srx_context* h, const void* ll, const int64_t* off, int64_t 
     if (rc) return rc;
     rc = srx_ws_ensure(h, WS_LATTICE, sizeof(T) * (size_t)n_frames * S, (void**)&delta);
     if (rc) return rc;
+    double* shift;
+    rc = srx_ws_ensure(h, WS_SCALE, sizeof(double) * (size_t)(U > 0 ? U : 1), (void**)&shift);
+    if (rc) return rc;
     T* logA = tabs;
     T* logAT = logA + (size_t)S * S;
     T* logpi = logAT + (size_t)S * S;
@@ -462,12 +499,12 @@ int viterbi_dense_t(srx_context* h, const void* ll, const int64_t* off, int64_t 
         SRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds16));
         hipLaunchKernelGGL(kern, dim3((unsigned)((U + UBmax - 1) / UBmax)), dim3(threads), lds16, st,
-                           (const T*)ll, off, U, S, logpi, logA, delta);
+                           (const T*)ll, off, U, S, logpi, logA, delta, shift);
     } else {
         return SRX_EUNSUPPORTED;
     }
     hipLaunchKernelGGL(viterbi_backtrace_kernel<T>, dim3((unsigned)((U + 3) / 4)), dim3(256), 0, st,
-                       (const T*)delta, off, U, S, logAT, path, lp);
+                       (const T*)delta, off, U, S, logAT, (const double*)shift, path, lp);
     SRX_HIP(hipGetLastError());
     return SRX_OK;
 }

@@ -103,6 +103,25 @@ def test_dense_viterbi_large_states(sra, ctx, S):
     assert _rel(lp32.cpu().numpy(), rlp) < 1e-5
 
 
+def test_dense_viterbi_float32_long_utterances(sra, ctx):
+    """Utterances of thousands of frames through the dense float32 Viterbi: the lattice is
+    made relative to its maximum every 64 steps, so paths part from the float64 ones only at
+    near-ties (1e-6 of the score) and the log-probability keeps 1e-6 relative."""
+    rng = np.random.default_rng(77)
+    S = 40
+    lengths = [5000, 1, 2049, 33, 17, 3000] + [16] * 12
+    ll = (rng.standard_normal((sum(lengths), S)) * 3.0 - 50.0).astype(np.float32).astype(np.float64)
+    A = rng.dirichlet(np.ones(S) * 0.3, size=S)
+    pi = rng.dirichlet(np.ones(S))
+    rlp, rpath = ho.viterbi_dense(pi, A, ll, lengths)
+    off = ctx.tensor(np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64))
+    lp32, path32 = sra.viterbi_dense(ctx, ctx.tensor(ll.astype(np.float32)), off, pi, A)
+    n_diff, gap, short = assert_ties_only(pi, A, ll, lengths, path32.cpu().numpy(), rpath, rlp, eps=1e-6)
+    print(f"dense viterbi float32, {sum(lengths)} frames: {n_diff} differ, largest tie gap {gap:.2e}")
+    assert n_diff <= 40
+    assert _rel(lp32.cpu().numpy(), rlp) < 1e-6
+
+
 def test_large_model_errors(sra, ctx):
     with pytest.raises(ValueError):
         sra.GmmEmission(ctx, np.ones((2, 2)), np.zeros((2, 3, 4)), np.ones((2, 3, 4)))
