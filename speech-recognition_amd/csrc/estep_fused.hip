@@ -584,46 +584,73 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
     }
 }
 
-// Lattice row bases: frames per batch of 16 utterances (in processing order),
-// then an exclusive prefix sum by one block.
-__global__ void fused_batch_total_kernel(const int64_t* __restrict__ off, int64_t U,
-                                         const int64_t* __restrict__ utt_order, int64_t n_batches,
-                                         int64_t* __restrict__ base) {
+// Lattice row bases: the exclusive prefix sum of the frames per batch of 16 utterances (in
+// processing order), in three short kernels with coalesced accesses:
+//   fused_batch_total_kernel  frames of each batch, and the sum over each workgroup's 256 batches
+//   fused_block_scan_kernel   exclusive prefix of those workgroup sums (one workgroup)
+//   fused_batch_base_kernel   prefix inside the workgroup + the workgroup's prefix
+__global__ __launch_bounds__(256) void fused_batch_total_kernel(const int64_t* __restrict__ off, int64_t U,
+                                                                const int64_t* __restrict__ utt_order,
+                                                                int64_t n_batches, int64_t* __restrict__ base,
+                                                                int64_t* __restrict__ block_sum) {
+    __shared__ int64_t part[4];
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_batches) return;
     int64_t sum = 0;
-    for (int j = 0; j < 16; ++j) {
-        const int64_t e = b * 16 + j;
-        if (e < U) {
-            const int64_t u = utt_order ? utt_order[e] : e;
-            if (u >= 0) sum += off[u + 1] - off[u];
+    if (b < n_batches) {
+        for (int j = 0; j < 16; ++j) {
+            const int64_t e = b * 16 + j;
+            if (e < U) {
+                const int64_t u = utt_order ? utt_order[e] : e;
+                if (u >= 0) sum += off[u + 1] - off[u];
+            }
         }
+        base[b] = sum;
     }
-    base[b] = sum;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
-__global__ __launch_bounds__(1024) void fused_batch_scan_kernel(int64_t n_batches,
-                                                                int64_t* __restrict__ base) {
+__global__ __launch_bounds__(1024) void fused_block_scan_kernel(int64_t n, int64_t* __restrict__ v) {
     __shared__ int64_t part[1024];
     const int tid = threadIdx.x;
-    const int64_t per = (n_batches + 1023) / 1024;
-    const int64_t b0 = tid * per, b1 = b0 + per < n_batches ? b0 + per : n_batches;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t b0 = tid * per, b1 = b0 + per < n ? b0 + per : n;
     int64_t sum = 0;
-    for (int64_t b = b0; b < b1; ++b) sum += base[b];
+    for (int64_t b = b0; b < b1; ++b) sum += v[b];
     part[tid] = sum;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
-        const int64_t v = tid >= o ? part[tid - o] : 0;
+        const int64_t x = tid >= o ? part[tid - o] : 0;
         __syncthreads();
-        part[tid] += v;
+        part[tid] += x;
         __syncthreads();
     }
     int64_t run = part[tid] - sum;
     for (int64_t b = b0; b < b1; ++b) {
-        const int64_t v = base[b];
-        base[b] = run;
-        run += v;
+        const int64_t x = v[b];
+        v[b] = run;
+        run += x;
     }
+}
+
+__global__ __launch_bounds__(256) void fused_batch_base_kernel(int64_t n_batches, const int64_t* __restrict__ block_pre,
+                                                               int64_t* __restrict__ base) {
+    __shared__ int64_t part[256];
+    const int tid = threadIdx.x;
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + tid;
+    const int64_t mine = b < n_batches ? base[b] : 0;
+    part[tid] = mine;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int64_t x = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += x;
+        __syncthreads();
+    }
+    if (b < n_batches) base[b] = block_pre[blockIdx.x] + part[tid] - mine;
 }
 
 // Sum the replicas in fixed order, apply A to the xi accumulator.
@@ -875,10 +902,14 @@ int srx_fused_estep(srx_context* h, const void* X, const int64_t* off, int64_t U
     if (utt_order == nullptr && (rc = build_model_order(h, utt_model, off, U, M, st, &utt_order, &E))) return rc;
     const int64_t n_batches = (E + 15) / 16;
     int64_t* batch_base;
-    if ((rc = srx_ws_ensure(h, WS_MISC, sizeof(int64_t) * (size_t)n_batches, (void**)&batch_base))) return rc;
-    hipLaunchKernelGGL(fused_batch_total_kernel, dim3((unsigned)((n_batches + 255) / 256)), dim3(256),
-                       0, st, off, E, utt_order, n_batches, batch_base);
-    hipLaunchKernelGGL(fused_batch_scan_kernel, dim3(1), dim3(1024), 0, st, n_batches, batch_base);
+    const int64_t n_blk = (n_batches + 255) / 256;
+    if ((rc = srx_ws_ensure(h, WS_MISC, sizeof(int64_t) * (size_t)(n_batches + n_blk), (void**)&batch_base))) return rc;
+    int64_t* block_sum = batch_base + n_batches;
+    hipLaunchKernelGGL(fused_batch_total_kernel, dim3((unsigned)n_blk), dim3(256), 0, st, off, E, utt_order,
+                       n_batches, batch_base, block_sum);
+    hipLaunchKernelGGL(fused_block_scan_kernel, dim3(1), dim3(1024), 0, st, n_blk, block_sum);
+    hipLaunchKernelGGL(fused_batch_base_kernel, dim3((unsigned)n_blk), dim3(256), 0, st, n_batches,
+                       (const int64_t*)block_sum, batch_base);
     hipLaunchKernelGGL(fused_prep_kernel, dim3(24), dim3(256), 0, st, *md, RQ, H, base, cst, A, pi);
     const float* Xf = (const float*)X;
 #define SRX_CASE(rq, hh, ntx)                                                                \
@@ -935,10 +966,14 @@ int srx_fused_posteriors(srx_context* h, const void* X, const int64_t* off, int6
     if ((rc = build_model_order(h, utt_model, off, U, M, st, &order, &E))) return rc;
     const int64_t n_batches = (E + 15) / 16;
     int64_t* batch_base;
-    if ((rc = srx_ws_ensure(h, WS_MISC, sizeof(int64_t) * (size_t)n_batches, (void**)&batch_base))) return rc;
-    hipLaunchKernelGGL(fused_batch_total_kernel, dim3((unsigned)((n_batches + 255) / 256)), dim3(256),
-                       0, st, off, E, order, n_batches, batch_base);
-    hipLaunchKernelGGL(fused_batch_scan_kernel, dim3(1), dim3(1024), 0, st, n_batches, batch_base);
+    const int64_t n_blk = (n_batches + 255) / 256;
+    if ((rc = srx_ws_ensure(h, WS_MISC, sizeof(int64_t) * (size_t)(n_batches + n_blk), (void**)&batch_base))) return rc;
+    int64_t* block_sum = batch_base + n_batches;
+    hipLaunchKernelGGL(fused_batch_total_kernel, dim3((unsigned)n_blk), dim3(256), 0, st, off, E, order,
+                       n_batches, batch_base, block_sum);
+    hipLaunchKernelGGL(fused_block_scan_kernel, dim3(1), dim3(1024), 0, st, n_blk, block_sum);
+    hipLaunchKernelGGL(fused_batch_base_kernel, dim3((unsigned)n_blk), dim3(256), 0, st, n_batches,
+                       (const int64_t*)block_sum, batch_base);
     hipLaunchKernelGGL(fused_prep_kernel, dim3(24), dim3(256), 0, st, *md, RQ, H, base, cst, A, pi);
     const float* Xf = (const float*)X;
 #define SRX_CASE(rq, hh)                                                                         \
