@@ -270,10 +270,13 @@ int srx_viterbi_dense(srx_handle_t h, const void* loglik, int dtype, const int64
 /* ---- Baum-Welch E-step: do_estep + fit_scaling +
  * accumulate_sufficient_statistics(_scaling), hmm.py:419-433, :330-354,
  * :237-253, utils.py:132-218.  Every utterance contributes to the record of
- * its model utt_model[u] (NULL = model 0).  utt_order (NULL = 0..U-1) is the
- * order utterances are visited in; a permutation that groups the utterances
- * of one model together makes the accumulation cheaper and changes nothing
- * but the summation order.  out_stats[n_models, stats_size] is overwritten. */
+ * its model utt_model[u] (NULL = model 0).  utt_order is the order utterances
+ * are visited in; a permutation that groups the utterances of one model (and,
+ * inside a model, of similar length) together makes the accumulation cheaper
+ * and changes nothing but the summation order.  With utt_order NULL the
+ * float32 kernels build that order on the device themselves (a counting sort
+ * by model and length bucket; nothing for the caller to do), the float64
+ * kernels visit 0..U-1.  out_stats[n_models, stats_size] is overwritten. */
 int srx_estep_stats(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
                     int64_t n_utts, int64_t n_frames, const int32_t* utt_model,
                     const int64_t* utt_order, const srx_models_t* models, double* out_stats,
