@@ -121,9 +121,15 @@ int srx_destroy(srx_handle_t h);
  * SRX_ESTEP_LANE (2) ask for one of the two wherever its limits allow (tests, timing).
  * The results agree to float32 rounding.  SRX_F64 data: small jobs take one lane per
  * utterance too (at most 4 states, 4096 utterances); SRX_ESTEP_FUSED keeps them on the
- * sub-wave chain kernels every other float64 job runs on. */
-enum srx_option { SRX_OPT_EXACT_F32 = 1, SRX_OPT_ESTEP_PATH = 2 };
+ * sub-wave chain kernels every other float64 job runs on.
+ * SRX_OPT_VITERBI_PATH chooses the kernels of SRX_F32 srx_viterbi for models of 5 to 8 states
+ * and at most 48 features: SRX_VITERBI_AUTO (0, default) decodes large batches (enough groups
+ * of 16 utterances to fill the GPU) in one kernel that keeps the log-densities on the chip and
+ * everything else in two (log-densities to memory, then the recursion); SRX_VITERBI_FUSED (1)
+ * and SRX_VITERBI_SPLIT (2) ask for one of the two (tests, timing).  Same paths, ties included. */
+enum srx_option { SRX_OPT_EXACT_F32 = 1, SRX_OPT_ESTEP_PATH = 2, SRX_OPT_VITERBI_PATH = 3 };
 enum srx_estep_path { SRX_ESTEP_AUTO = 0, SRX_ESTEP_FUSED = 1, SRX_ESTEP_LANE = 2 };
+enum srx_viterbi_path { SRX_VITERBI_AUTO = 0, SRX_VITERBI_FUSED = 1, SRX_VITERBI_SPLIT = 2 };
 int srx_set_option(srx_handle_t h, int option, int value);
 /* Bytes of scratch currently held by the context (diagnostics). */
 int64_t srx_workspace_bytes(srx_handle_t h);

@@ -18,6 +18,8 @@ SRX_F32, SRX_F64 = 0, 1
 SRX_MSTEP_FULL, SRX_MSTEP_TRANSITIONS_ONLY = 0, 1
 SRX_OPT_EXACT_F32 = 1
 SRX_OPT_ESTEP_PATH = 2
+SRX_OPT_VITERBI_PATH = 3
+SRX_VITERBI_AUTO, SRX_VITERBI_FUSED, SRX_VITERBI_SPLIT = 0, 1, 2
 SRX_ESTEP_AUTO, SRX_ESTEP_FUSED, SRX_ESTEP_LANE = 0, 1, 2
 SRX_EINVAL, SRX_EHIP, SRX_ENOMEM, SRX_EUNSUPPORTED = -1, -2, -3, -4
 

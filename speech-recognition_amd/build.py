@@ -11,11 +11,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsrx.so")
-SOURCES = ["api.hip", "hmm_generic.hip", "score_mfma.hip", "score_split8.hip", "score_split4.hip", "score_split16.hip", "score_f64.hip", "estep_fused.hip", "mfcc.hip", "mfcc_fast.hip", "large_model.hip", "endpoint.hip"]
+SOURCES = ["api.hip", "hmm_generic.hip", "score_mfma.hip", "score_split8.hip", "score_split4.hip", "score_split16.hip", "score_f64.hip", "estep_fused.hip", "viterbi_fused.hip", "mfcc.hip", "mfcc_fast.hip", "large_model.hip", "endpoint.hip"]
 # Packed f32 vector instructions (what SLP vectorisation makes of adjacent adds and
 # multiplies) issue slower than the two plain ones beside matrix instructions.
 FILE_FLAGS = {"score_mfma.hip": ["-fno-slp-vectorize"], "score_split8.hip": ["-fno-slp-vectorize"],
-              "score_split4.hip": ["-fno-slp-vectorize"], "score_split16.hip": ["-fno-slp-vectorize"]}
+              "score_split4.hip": ["-fno-slp-vectorize"], "score_split16.hip": ["-fno-slp-vectorize"],
+              "viterbi_fused.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall",
          "-Wno-unused-function", "-fvisibility=default",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC]

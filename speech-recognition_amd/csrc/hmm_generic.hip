@@ -1338,6 +1338,11 @@ int viterbi_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int6
     Tables<T> tb;
     int rc = prepare<T>(h, md, &tb, st);
     if (rc) return rc;
+    if constexpr (std::is_same<T, float>::value) {
+        // emission and recursion in one kernel where the shape allows it
+        rc = srx_fused_viterbi(h, X, off, U, n_frames, utt_model, md, tb.logA, tb.logpi, path, lp, st);
+        if (rc != SRX_EUNSUPPORTED) return rc;
+    }
     T* ll;
     uint8_t* bp;
     rc = srx_ws_ensure(h, WS_LOGLIK, sizeof(T) * (size_t)n_frames * S, (void**)&ll);

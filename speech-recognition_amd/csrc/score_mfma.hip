@@ -321,20 +321,30 @@ __global__ __launch_bounds__(256) void emission_split_kernel(
 
 // Emission log-densities of each utterance under ITS model only (Viterbi's input):
 // out[frame][state], natural log.  The table holds one 16-row tile per model; a
-// wave walks utterances, 16 consecutive frames per step.
-template <int RQ>
+// wave walks utterances, 16 consecutive frames per step.  The feature axis is cut as in
+// the scoring kernel (RQ blocks of 16 features and, if H, a last block of 8 whose operand
+// carries hi and lo halves), and the three kinds of partial product have an accumulator
+// each -- term for term the arithmetic of the fused Viterbi kernel (viterbi_fused.hip), so
+// that the two paths decode to the same states and log-probabilities bit for bit.
+template <int RQ, int H>
 __global__ __launch_bounds__(256) void emission_utt_split_kernel(
     const float* __restrict__ X, const int64_t* __restrict__ off, int64_t U, int64_t n_frames,
     const int32_t* __restrict__ utt_model, int S, int D, SplitTables tb, float* __restrict__ out) {
+    constexpr int QT = RQ + H;
+    struct item_t {
+        u32x4 v[RQ ? RQ : 1];
+        u32x2 h;
+    };
     const int lane = threadIdx.x & 63, g = lane >> 4, ul = lane & 15;
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const unsigned lane_off = (unsigned)ul * (unsigned)D * 4u + 16u * g;
+    const unsigned half_off = (unsigned)ul * (unsigned)D * 4u + 64u * RQ + 8u * g;
     int cur = -1;
-    u32x4 wh[RQ], wl[RQ];
+    u32x4 wh[QT], wl[QT];
     f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < RQ; ++q) wh[q] = wl[q] = u32x4{0u, 0u, 0u, 0u};
+    for (int q = 0; q < QT; ++q) wh[q] = wl[q] = u32x4{0u, 0u, 0u, 0u};
     for (int64_t u = wid; u < U; u += n_waves) {
         const int m = utt_model ? utt_model[u] : 0;
         const int64_t f0 = off[u];
@@ -343,8 +353,8 @@ __global__ __launch_bounds__(256) void emission_utt_split_kernel(
         if (m != cur) {
             cur = m;
 #pragma unroll
-            for (int q = 0; q < RQ; ++q) {
-                const unsigned* p = tb.Wp + ((((size_t)(m * 16 + ul)) * RQ + q) * 2 * 4 + g) * 4;
+            for (int q = 0; q < QT; ++q) {
+                const unsigned* p = tb.Wp + ((((size_t)(m * 16 + ul)) * QT + q) * 2 * 4 + g) * 4;
                 wh[q] = *(const u32x4*)p;
                 wl[q] = *(const u32x4*)(p + 16);
             }
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(256) void emission_utt_split_kernel(
             for (int r = 0; r < 4; ++r) c0[r] = tb.cst[m * 16 + 4 * g + r];
         }
         const int64_t n_groups = (T + 15) / 16;
-        auto load = [&](int64_t k, u32x4 (&dst)[RQ]) {
+        auto load = [&](int64_t k, item_t& dst) {
             // descriptor over [first frame of the group, end of the utterance)
             const int64_t fk = k < n_groups ? f0 + k * 16 : f0;
             const int64_t rest = k < n_groups ? (f0 + T - fk) * (int64_t)D * 4 : 0;
@@ -364,21 +374,28 @@ __global__ __launch_bounds__(256) void emission_utt_split_kernel(
                 (void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
 #pragma unroll
             for (int q = 0; q < RQ; ++q)
-                dst[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off + 64u * q, 0, 0);
+                dst.v[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off + 64u * q, 0, 0);
+            if constexpr (H != 0) dst.h = __builtin_amdgcn_raw_buffer_load_b64(rsrc, half_off, 0, 0);
         };
-        u32x4 xa[RQ], xb[RQ];
+        item_t xa, xb;
         load(0, xa);
         for (int64_t k = 0; k < n_groups; ++k) {
             load(k + 1, xb);
-            f32x4 acc = c0;
+            f32x4 acc = c0, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < RQ; ++q) {
                 bf16x8 bh, bl;
-                split_operand(xa[q], bh, bl);
+                split_operand(xa.v[q], bh, bl);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wh[q]), bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wh[q]), bl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wl[q]), bh, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wh[q]), bl, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wl[q]), bh, acc2, 0, 0, 0);
             }
+            if constexpr (H != 0) {
+                const bf16x8 bb = split_half_operand(xa.h);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wh[RQ]), bb, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wl[RQ]), bb, acc2, 0, 0, 0);
+            }
+            acc += acc1 + acc2;
             const int64_t t = k * 16 + ul;
             if (t < T) {
                 float* o = out + (f0 + t) * S;
@@ -392,8 +409,7 @@ __global__ __launch_bounds__(256) void emission_utt_split_kernel(
                         if (col + r < S) o[col + r] = v[r];
                 }
             }
-#pragma unroll
-            for (int q = 0; q < RQ; ++q) xa[q] = xb[q];
+            xa = xb;
         }
     }
 }
@@ -570,8 +586,9 @@ int srx_mfma_emission_utt(srx_context* h, const void* X, const int64_t* off, int
                           float* out, hipStream_t st) {
     const int M = md->n_models, S = md->n_states, D = md->n_features;
     if (h->exact_f32 || S > 16 || D > 48 || M > 4096 || n_frames <= 0 || U <= 0) return SRX_EUNSUPPORTED;
-    const int NT = M, RQ = (D + 15) / 16;
-    const size_t n_wp = (size_t)NT * 16 * RQ * 2 * 4 * 4, n_c = (size_t)NT * 16;
+    const int H = (D % 16 >= 1 && D % 16 <= 8) ? 1 : 0;
+    const int NT = M, RQ = H ? D / 16 : (D + 15) / 16, QT = RQ + H;
+    const size_t n_wp = (size_t)NT * 16 * QT * 2 * 4 * 4, n_c = (size_t)NT * 16;
     unsigned* base;
     int rc = srx_ws_ensure(h, WS_MISC, 4 * (n_wp + n_c + (size_t)M * S * S + (size_t)M * S),
                            (void**)&base);
@@ -582,19 +599,19 @@ int srx_mfma_emission_utt(srx_context* h, const void* X, const int64_t* off, int
     float* pi = A + (size_t)M * S * S;
     tb.Wp = base; tb.cst = cst; tb.A = A; tb.pi = pi; tb.order = nullptr;
     // one 16-row tile per model
-    hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, 16, NT, RQ, 0, base, cst, A, pi);
+    hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, 16, NT, RQ, H, base, cst, A, pi);
     int64_t gx = (U + 3) / 4;
     const int64_t cap = (int64_t)h->n_cu * 8;
     if (gx > cap) gx = cap;
     const float* Xf = (const float*)X;
-#define SRX_CASE(rq)                                                                          \
-    if (RQ == rq) {                                                                           \
-        hipLaunchKernelGGL((emission_utt_split_kernel<rq>), dim3((unsigned)gx), dim3(256), 0, \
-                           st, Xf, off, U, n_frames, utt_model, S, D, tb, out);               \
-        SRX_HIP(hipGetLastError());                                                           \
-        return SRX_OK;                                                                        \
+#define SRX_CASE(rq, hh)                                                                           \
+    if (RQ == rq && H == hh) {                                                                     \
+        hipLaunchKernelGGL((emission_utt_split_kernel<rq, hh>), dim3((unsigned)gx), dim3(256), 0,  \
+                           st, Xf, off, U, n_frames, utt_model, S, D, tb, out);                    \
+        SRX_HIP(hipGetLastError());                                                                \
+        return SRX_OK;                                                                             \
     }
-    SRX_CASE(3) SRX_CASE(2) SRX_CASE(1)
+    SRX_CASE(0, 1) SRX_CASE(1, 0) SRX_CASE(1, 1) SRX_CASE(2, 0) SRX_CASE(2, 1) SRX_CASE(3, 0)
 #undef SRX_CASE
     return SRX_EUNSUPPORTED;
 }

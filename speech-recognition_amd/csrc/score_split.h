@@ -476,6 +476,21 @@ __device__ __forceinline__ void split_operand(const u32x4& xc, bf16x8& bh, bf16x
     bl = __builtin_bit_cast(bf16x8, fl);
 }
 
+// Operand of the last block of 8 features, two per lane: hi halves in slots 0, 1 (x) and
+// 4, 5 (x^2), lo halves in slots 2, 3 and 6, 7 (the table repeats the hi weights there).
+__device__ __forceinline__ bf16x8 split_half_operand(const u32x2& xh) {
+    const float x0 = __uint_as_float(xh[0]), x1 = __uint_as_float(xh[1]);
+    const float s0 = x0 * x0, s1 = x1 * x1;
+    const bf16x2 a = {(__bf16)(x0 - __uint_as_float(xh[0] & 0xffff0000u)),
+                      (__bf16)(x1 - __uint_as_float(xh[1] & 0xffff0000u))};
+    const bf16x2 b = {(__bf16)(s0 - __uint_as_float(__float_as_uint(s0) & 0xffff0000u)),
+                      (__bf16)(s1 - __uint_as_float(__float_as_uint(s1) & 0xffff0000u))};
+    const u32x4 fb = {__builtin_amdgcn_perm(xh[1], xh[0], 0x07060302u), __builtin_bit_cast(unsigned, a),
+                      __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u),
+                      __builtin_bit_cast(unsigned, b)};
+    return __builtin_bit_cast(bf16x8, fb);
+}
+
 template <int SP, int NT, int RQ, int H>
 void launch_split(const float* X, const int64_t* off, int64_t U, int64_t n_frames, int M, int S,
                   int D, int chunks, SplitTables tb, double* out, hipStream_t st) {

@@ -25,6 +25,7 @@ struct srx_context {
     int n_cu;
     int exact_f32;   // SRX_OPT_EXACT_F32: keep the float32 paths on exact-f32 matrix instructions
     int estep_path;  // SRX_OPT_ESTEP_PATH
+    int viterbi_path;  // SRX_OPT_VITERBI_PATH
     void* ws[WS_NUM];
     size_t ws_bytes[WS_NUM];
     void* static_scratch;   // this device's copy of the fixed table array (api.hip)
@@ -179,6 +180,12 @@ int srx_fused_estep(srx_context* h, const void* X, const int64_t* off, int64_t U
 int srx_fused_posteriors(srx_context* h, const void* X, const int64_t* off, int64_t U,
                          int64_t n_frames, const int32_t* utt_model, const srx_models_t* md,
                          float* out_post, double* out_lp, hipStream_t st);
+
+// Implemented in viterbi_fused.hip (float32, 5 to 8 states, D <= 48): emission and max-plus
+// recursion in one kernel, else SRX_EUNSUPPORTED.  logA / logpi: float32 device tables.
+int srx_fused_viterbi(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
+                      const int32_t* utt_model, const srx_models_t* md, const float* logA,
+                      const float* logpi, int32_t* path, double* lp, hipStream_t st);
 
 // Implemented in mfcc_fast.hip (float32, nfft 512 / 1024), else SRX_EUNSUPPORTED.
 int srx_mfcc_fast_cepstra(srx_context* h, srx_mfcc_plan* plan, const float* audio,

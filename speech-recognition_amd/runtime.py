@@ -76,6 +76,14 @@ class Context:
         code = {"auto": _lib.SRX_ESTEP_AUTO, "fused": _lib.SRX_ESTEP_FUSED, "lane": _lib.SRX_ESTEP_LANE}[path]
         check(lib.srx_set_option(self._h, _lib.SRX_OPT_ESTEP_PATH, code), "srx_set_option")
 
+    def set_viterbi_path(self, path):
+        """Kernels of float32 Viterbi decoding for models of 5 to 8 states: "auto" (one fused
+        kernel for batches large enough to fill the GPU, emission + recursion kernels
+        otherwise), "fused" or "split"."""
+        code = {"auto": _lib.SRX_VITERBI_AUTO, "fused": _lib.SRX_VITERBI_FUSED,
+                "split": _lib.SRX_VITERBI_SPLIT}[path]
+        check(lib.srx_set_option(self._h, _lib.SRX_OPT_VITERBI_PATH, code), "srx_set_option")
+
     def workspace_bytes(self):
         return int(lib.srx_workspace_bytes(self._h))
 

@@ -947,3 +947,58 @@ def test_random_front_end_configurations_against_oracle():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "80 cases ok" in r.stdout
+
+
+@pytest.mark.parametrize("S,D", [(5, 7), (6, 13), (7, 24), (8, 26), (8, 39), (5, 48), (8, 40)])
+def test_viterbi_fused_kernel_matches_oracle(sra, ctx, S, D):
+    """The one-kernel float32 Viterbi (emission on the matrix cores, log-densities kept in LDS,
+    four lanes per utterance in the max-plus recursion) on multi-model ragged batches that
+    leave partial groups of 16 utterances and partial chunks of 16 frames, for every way the
+    feature axis is cut into blocks of 16 and 8: paths equal the float64 oracle's
+    (utils.py:243-266) except at near-ties, log-probabilities to 1e-5, and the two-kernel path
+    gives the same states and log-probabilities bit for bit."""
+    from conftest import assert_ties_only
+    rng = np.random.default_rng(100 * S + D)
+    M = 3
+    prms = [ho.random_params(rng, S, D) for _ in range(M)]
+    # a left-to-right model: structural zeros in the transition matrix and the start vector
+    A = np.triu(prms[1].A) * (np.tril(np.ones((S, S)), 1))
+    prms[1] = ho.Params(np.eye(S)[0], A / A.sum(axis=1, keepdims=True), prms[1].means, prms[1].covars)
+    lengths = np.array([0, 1, 2, 15, 16, 17, 33, 200, 64, 31, 1, 48, 5, 129, 16, 0, 7, 96, 32, 3, 250,
+                        18, 16, 160, 2, 80, 47, 49, 1, 100, 12, 65, 66, 15, 14, 201, 8], dtype=np.int64)
+    um = rng.integers(0, M, size=len(lengths)).astype(np.int32)
+    X = rng.standard_normal((int(lengths.sum()), D)).astype(np.float32).astype(np.float64)
+    bank = _bank(sra, ctx, prms)
+    data = sra.Ragged(ctx, X, lengths, dtype="float32")
+    got = {}
+    for which in ("fused", "split"):
+        ctx.set_viterbi_path(which)
+        try:
+            lp, path = bank.viterbi(data, um)
+        finally:
+            ctx.set_viterbi_path("auto")
+        got[which] = (lp.cpu().numpy(), path.cpu().numpy())
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    want_lp, want_path = np.zeros(len(lengths)), np.zeros(int(lengths.sum()), dtype=np.int64)
+    log_B = np.zeros((int(lengths.sum()), S))
+    for u, n in enumerate(lengths):
+        if n == 0:
+            continue
+        a, b = off[u], off[u + 1]
+        lp_u, want_path[a:b] = ho.viterbi(prms[um[u]], X[a:b])
+        want_lp[u] = float(np.asarray(lp_u).reshape(-1)[0])
+        log_B[a:b] = ho.log_density_diag(X[a:b], prms[um[u]].means, prms[um[u]].covars)
+    for which, (lp, path) in got.items():
+        for m in range(M):
+            sel = np.nonzero(um == m)[0]
+            # (assert_ties_only takes one model: check each model's utterances on their own)
+            idx = np.concatenate([np.arange(off[u], off[u + 1]) for u in sel]) if len(sel) else np.zeros(0, int)
+            n_diff, gap, short = assert_ties_only(prms[m].pi, prms[m].A, log_B[idx], lengths[sel], path[idx],
+                                                  want_path[idx], want_lp[sel])
+            assert n_diff <= 3, (which, m, n_diff)
+        nz = lengths > 0
+        assert np.abs(lp[nz] - want_lp[nz]).max() <= 1e-5 * np.abs(want_lp[nz]).max(), which
+        assert np.all(lp[~nz] == 0.0)
+    # the two paths do the same arithmetic term for term: which one a batch takes does not show
+    np.testing.assert_array_equal(got["fused"][1], got["split"][1])
+    np.testing.assert_array_equal(got["fused"][0], got["split"][0])
