@@ -15,9 +15,11 @@
 //              number of resident waves, and the emission needs three per SIMD to hide its
 //              dependent matrix instructions and LDS reads.)
 // The back-pointer words are the only intermediate that goes to memory (4 bytes per
-// frame); lane v resolves them backwards at the end, four frames per access.  Ties take the
+// frame); lane v resolves them backwards at the end, sixteen frames per access.  Ties take the
 // lowest state, as np.argmax does; delta is kept relative to its largest entry every four
-// frames (the shift is carried in float64 to the log-probability).
+// frames (the shift is carried in float64 to the log-probability).  The arithmetic is that of
+// emission_utt_split_kernel + viterbi_lane_kernel term for term: same states, same
+// log-probabilities, bit for bit.
 #include "score_split.h"
 
 namespace {
@@ -147,9 +149,9 @@ __global__ __launch_bounds__(1024) void viterbi_fused_kernel(
         if constexpr (H != 0) dst.h = __builtin_amdgcn_raw_buffer_load_b64(rsrc, half_off, 0, 0);
     };
     auto emit = [&](int k, int e, const item_t& x) {
-        // (no branch around an utterance that has ended: its loads returned zeros, its rows of
-        // the tile are not read, and four emissions in one basic block overlap each other's
-        // matrix and vector instructions)
+        // (an utterance that has ended is skipped: in a ragged group only the recursion's
+        // steps run on to the longest utterance's end)
+        if (16 * k >= __builtin_amdgcn_readlane(T, e)) return;
         const int me = __builtin_amdgcn_readlane(m, e);
         // (rows 8..15 of the product are never stored: their lanes read rows 0..7 again)
         const unsigned* wp = s_w + (size_t)me * (QT * 256) + g * 32 + (ul & 7) * 4;
