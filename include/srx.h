@@ -122,7 +122,7 @@ int srx_destroy(srx_handle_t h);
  * The results agree to float32 rounding.  SRX_F64 data: small jobs take one lane per
  * utterance too (at most 4 states, 4096 utterances); SRX_ESTEP_FUSED keeps them on the
  * sub-wave chain kernels every other float64 job runs on.
- * SRX_OPT_VITERBI_PATH chooses the kernels of SRX_F32 srx_viterbi for models of 5 to 8 states
+ * SRX_OPT_VITERBI_PATH chooses the kernels of SRX_F32 srx_viterbi for models of at most 8 states
  * and at most 48 features: SRX_VITERBI_AUTO (0, default) decodes large batches (enough groups
  * of 16 utterances to fill the GPU) in one kernel that keeps the log-densities on the chip and
  * everything else in two (log-densities to memory, then the recursion); SRX_VITERBI_FUSED (1)

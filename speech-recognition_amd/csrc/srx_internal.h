@@ -181,7 +181,7 @@ int srx_fused_posteriors(srx_context* h, const void* X, const int64_t* off, int6
                          int64_t n_frames, const int32_t* utt_model, const srx_models_t* md,
                          float* out_post, double* out_lp, hipStream_t st);
 
-// Implemented in viterbi_fused.hip (float32, 5 to 8 states, D <= 48): emission and max-plus
+// Implemented in viterbi_fused.hip (float32, at most 8 states, D <= 48): emission and max-plus
 // recursion in one kernel, else SRX_EUNSUPPORTED.  logA / logpi: float32 device tables.
 int srx_fused_viterbi(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
                       const int32_t* utt_model, const srx_models_t* md, const float* logA,

@@ -1,4 +1,4 @@
-// Fused Viterbi decoding for models of 5 to 8 states, float32 (utils.py:243-266 of the
+// Fused Viterbi decoding for models of at most 8 states, float32 (utils.py:243-266 of the
 // reference with the emission of hmm.py:154-163 in front of it): the log-densities never
 // go through global memory.
 //
@@ -336,13 +336,13 @@ __global__ __launch_bounds__(1024) void viterbi_fused_kernel(
 }  // namespace
 
 // Float32 Viterbi of every utterance under its own model without a log-density array
-// (5 to 8 states, at most 48 features, model tables that fit the LDS); SRX_EUNSUPPORTED
+// (at most 8 states, at most 48 features, model tables that fit the LDS); SRX_EUNSUPPORTED
 // for every other job.  logA / logpi: [M][S][S] / [M][S] float32 on the device.
 int srx_fused_viterbi(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
                       const int32_t* utt_model, const srx_models_t* md, const float* logA,
                       const float* logpi, int32_t* path, double* lp, hipStream_t st) {
     const int M = md->n_models, S = md->n_states, D = md->n_features;
-    if (h->exact_f32 || h->viterbi_path == SRX_VITERBI_SPLIT || S < 5 || S > 8 || D > 48 ||
+    if (h->exact_f32 || h->viterbi_path == SRX_VITERBI_SPLIT || S < 1 || S > 8 || D > 48 ||
         n_frames <= 0 || U <= 0)
         return SRX_EUNSUPPORTED;
     const int H = (D % 16 >= 1 && D % 16 <= 8) ? 1 : 0;
@@ -405,7 +405,7 @@ int srx_fused_viterbi(srx_context* h, const void* X, const int64_t* off, int64_t
 #define SRX_CASES(s_)                                                                            \
     SRX_CASE(s_, 0, 1) SRX_CASE(s_, 1, 0) SRX_CASE(s_, 1, 1) SRX_CASE(s_, 2, 0) SRX_CASE(s_, 2, 1) \
     SRX_CASE(s_, 3, 0)
-    SRX_CASES(5) SRX_CASES(6) SRX_CASES(7) SRX_CASES(8)
+    SRX_CASES(1) SRX_CASES(2) SRX_CASES(3) SRX_CASES(4) SRX_CASES(5) SRX_CASES(6) SRX_CASES(7) SRX_CASES(8)
 #undef SRX_CASES
 #undef SRX_CASE
     return SRX_EUNSUPPORTED;

@@ -949,7 +949,7 @@ def test_random_front_end_configurations_against_oracle():
     assert "80 cases ok" in r.stdout
 
 
-@pytest.mark.parametrize("S,D", [(5, 7), (6, 13), (7, 24), (8, 26), (8, 39), (5, 48), (8, 40)])
+@pytest.mark.parametrize("S,D", [(1, 5), (2, 13), (3, 26), (4, 39), (5, 7), (6, 13), (7, 24), (8, 26), (8, 39), (5, 48), (8, 40)])
 def test_viterbi_fused_kernel_matches_oracle(sra, ctx, S, D):
     """The one-kernel float32 Viterbi (emission on the matrix cores, log-densities kept in LDS,
     four lanes per utterance in the max-plus recursion) on multi-model ragged batches that

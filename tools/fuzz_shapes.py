@@ -13,6 +13,8 @@ dtype = sys.argv[3] if len(sys.argv) > 3 else "float32"
 max_u = int(sys.argv[4]) if len(sys.argv) > 4 else 40      # more than 32 utterances: visiting orders are made
 tight = 1e-6 if dtype == "float64" else 1.0
 ctx = sra.Context.default(0)
+if os.environ.get("SRX_VITERBI_PATH"):          # "fused" / "split": one of the two float32 Viterbi paths
+    ctx.set_viterbi_path(os.environ["SRX_VITERBI_PATH"])
 rng = np.random.default_rng(seed)
 worst = {"score": 0.0, "post": 0.0, "stats": 0.0}
 for case in range(n_cases):

@@ -6,8 +6,10 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 U = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 dtype = sys.argv[4] if len(sys.argv) > 4 else "float32"
-D, M = 39, 6
+D, M = int(os.environ.get("VB_D", "39")), 6
 ctx = sra.Context.default(0)
+if os.environ.get("SRX_VITERBI_PATH"):
+    ctx.set_viterbi_path(os.environ["SRX_VITERBI_PATH"])
 X = torch.randn((U * T, D), device='cuda', dtype=torch.float32)
 off = torch.arange(0, (U + 1) * T, T, device='cuda', dtype=torch.int64)
 data = sra.Ragged(ctx, X.double() if dtype == "float64" else X, offsets=off, dtype=dtype)
