@@ -24,7 +24,8 @@
 
 namespace {
 
-constexpr int kUttPerWave = 16;
+constexpr int kTcap = 256;                 // frames whose back-pointer words a wave of 8 utterances keeps in LDS
+constexpr int kWordStride = kTcap + 4;      // words per utterance there (+4: bank spread)
 constexpr int kTileStride = 16 * 8 + 4;     // floats per utterance in the tile (+4: bank spread)
 
 __device__ __forceinline__ void wave_sync() {
@@ -62,13 +63,19 @@ __device__ __forceinline__ float rows_max(float v) {
     return fmaxf(a, b);
 }
 
-template <int S, int RQ, int H>
+template <int S, int RQ, int H, int UPW>
 __global__ __launch_bounds__(1024) void viterbi_fused_kernel(
     const float* __restrict__ X, const int64_t* __restrict__ off, int64_t U,
     const int32_t* __restrict__ utt_model, int M, int D, SplitTables tb,
     const float* __restrict__ logA, const float* __restrict__ logpi, uint32_t* __restrict__ bpw,
     int32_t* __restrict__ path, double* __restrict__ out_lp) {
     static_assert(S >= 1 && S <= 8, "four lanes of two states each");
+    static_assert(UPW == 16 || UPW == 8, "utterances per wave");
+    // UPW = 8: half of the recursion's lanes idle, but the tile is half as large and the
+    // back-pointer words of utterances of up to kTcap frames fit beside it in LDS -- no store
+    // goes out between the loads of the feature stream (what even 4 bytes per frame of them
+    // cost: tools/probes/chunk_stream.hip) and the backtrace reads no memory.
+    constexpr int kWaveFloats = UPW * kTileStride + (UPW == 8 ? UPW * kWordStride : 0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // The feature axis is cut as in the scoring kernel: RQ blocks of 16 features and, if H, a
     // last block of 8 whose operand carries hi and lo halves at once (a row of 33..40 features is
@@ -95,13 +102,14 @@ __global__ __launch_bounds__(1024) void viterbi_fused_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, ul = lane & 15;         // emission: lane group, frame of the chunk
     const int h = lane >> 4, v = lane & 15;          // recursion: pair of states, utterance
-    float* tile = s_tiles + wave * (kUttPerWave * kTileStride);
-    // groups of 16 utterances are dealt to the waves of the grid in turn
-    const int64_t n_groups = (U + kUttPerWave - 1) / kUttPerWave;
+    float* tile = s_tiles + wave * kWaveFloats;
+    uint32_t* wl = (uint32_t*)(tile + UPW * kTileStride);     // [UPW][kWordStride] (UPW = 8)
+    // groups of UPW utterances are dealt to the waves of the grid in turn
+    const int64_t n_groups = (U + UPW - 1) / UPW;
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
     for (int64_t grp = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; grp < n_groups; grp += n_waves) {
-    const int64_t u = grp * kUttPerWave + v;
-    const bool valid = u < U;
+    const int64_t u = grp * UPW + v;
+    const bool valid = v < UPW && u < U;
     const int64_t f0 = valid ? off[u] : 0;
     const int T = valid ? (int)(off[u + 1] - f0) : 0;
     const int m = valid && utt_model ? utt_model[u] : 0;
@@ -113,7 +121,8 @@ __global__ __launch_bounds__(1024) void viterbi_fused_kernel(
         continue;
     }
     const int n_chunks = (Tmax + 15) >> 4;
-    const int n_items = n_chunks * kUttPerWave;
+    const int n_items = n_chunks * UPW;
+    const bool words_in_lds = UPW == 8 && Tmax <= kTcap;      // (the same for the whole wave)
 
     // log A columns of this lane's states (state 2 h + jj), -inf for states the model lacks
     float la[S][2], d[2];
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(1024) void viterbi_fused_kernel(
     const unsigned lane_off = (unsigned)ul * (unsigned)D * 4u + 16u * g;
     const unsigned half_off = (unsigned)ul * (unsigned)D * 4u + 64u * RQ + 8u * g;
     auto issue = [&](int i, item_t& dst) {
-        const int k = i >> 4, e = i & 15;
+        const int k = i / UPW, e = i % UPW;
         const int Te = __builtin_amdgcn_readlane(T, e);
         const uint64_t fe = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)f0_hi, e) << 32) |
                             (unsigned)__builtin_amdgcn_readlane((int)f0_lo, e);
@@ -226,8 +235,8 @@ __global__ __launch_bounds__(1024) void viterbi_fused_kernel(
     issue(3, x3);
     for (int k = 0; k < n_chunks; ++k) {
 #pragma unroll 1
-        for (int e4 = 0; e4 < kUttPerWave; e4 += 4) {
-            const int i = k * kUttPerWave + e4;
+        for (int e4 = 0; e4 < UPW; e4 += 4) {
+            const int i = k * UPW + e4;
             emit(k, e4, x0);
             issue(i + 4, x0);
             emit(k, e4 + 1, x1);
@@ -267,7 +276,10 @@ __global__ __launch_bounds__(1024) void viterbi_fused_kernel(
                 }
             }
             const int t0 = 16 * k + t4;
-            if (h == 0) {
+            if (words_in_lds) {
+                // (every utterance has its own kTcap words: what lies past its end is never read)
+                if (h == 0 && v < UPW) *(u32x4*)(wl + v * kWordStride + t0) = u32x4{w[0], w[1], w[2], w[3]};
+            } else if (h == 0) {
                 if (t0 + 3 < T) {
                     struct __attribute__((packed, aligned(4))) Words4 { uint32_t v[4]; };
                     *(Words4*)(bw + t0) = Words4{{w[0], w[1], w[2], w[3]}};
@@ -312,24 +324,28 @@ __global__ __launch_bounds__(1024) void viterbi_fused_kernel(
     struct __attribute__((packed, aligned(4))) Words16 { uint32_t v[16]; };
     int32_t* p = path + f0;
     p[T - 1] = s;
-    int t = T - 1;                       // frame whose word is looked up next
-    Words16 cur, nxt;
-    if (t >= 16) cur = *(const Words16*)(bw + t - 15);
-    for (; t >= 16; t -= 16) {
-        if (t >= 32) nxt = *(const Words16*)(bw + t - 31);   // words of frames t-31 .. t-16
-        Words16 o;
+    auto backtrace = [&](const auto* words) {
+        int t = T - 1;                       // frame whose word is looked up next
+        Words16 cur, nxt;
+        if (t >= 16) cur = *(const Words16*)(words + t - 15);
+        for (; t >= 16; t -= 16) {
+            if (t >= 32) nxt = *(const Words16*)(words + t - 31);   // words of frames t-31 .. t-16
+            Words16 o;
 #pragma unroll
-        for (int k = 15; k >= 0; --k) {
-            s = (int)((cur.v[k] >> (3 * s)) & 7u);            // cur: words of frames t-15 .. t
-            o.v[k] = (uint32_t)s;                             // state of frame t-16+k
+            for (int k = 15; k >= 0; --k) {
+                s = (int)((cur.v[k] >> (3 * s)) & 7u);            // cur: words of frames t-15 .. t
+                o.v[k] = (uint32_t)s;                             // state of frame t-16+k
+            }
+            *(Words16*)(p + t - 16) = o;
+            cur = nxt;
         }
-        *(Words16*)(p + t - 16) = o;
-        cur = nxt;
-    }
-    for (; t >= 1; --t) {
-        s = (int)((bw[t] >> (3 * s)) & 7u);
-        p[t - 1] = s;
-    }
+        for (; t >= 1; --t) {
+            s = (int)((words[t] >> (3 * s)) & 7u);
+            p[t - 1] = s;
+        }
+    };
+    if (words_in_lds) backtrace(wl + v * kWordStride);
+    else backtrace(bw);
     }   // groups
 }
 
@@ -348,11 +364,16 @@ int srx_fused_viterbi(srx_context* h, const void* X, const int64_t* off, int64_t
     const int H = (D % 16 >= 1 && D % 16 <= 8) ? 1 : 0;
     const int RQ = H ? D / 16 : (D + 15) / 16, QT = RQ + H;
     const size_t w_bytes = (size_t)M * QT * 2 * 4 * 8 * 16 + 4 * (size_t)((M * 8 + 3) & ~3);
+    // Utterances per wave: 8 with the back-pointer words in LDS when the utterances are short
+    // enough on average for most groups to fit (a group with a longer one spills its words like
+    // the 16-utterance variant does), else 16.
+    const int UPW = n_frames / U <= kTcap * 3 / 4 ? 8 : 16;
     // waves per workgroup and workgroups per CU: as many resident waves as the LDS holds (the
     // model tables once per workgroup, a tile per wave), at most 16 (the kernel has 128 registers)
-    const size_t tile_bytes = (size_t)kUttPerWave * kTileStride * 4, lds_cu = 160 * 1024;
+    const size_t tile_bytes = 4 * ((size_t)UPW * kTileStride + (UPW == 8 ? (size_t)UPW * kWordStride : 0));
+    const size_t lds_cu = 160 * 1024;
     int wpb = 0, per_cu = 0;
-    for (int w = 16; w >= 4; w >>= 1) {
+    for (int w = 16; w >= 4; --w) {
         const size_t need = w_bytes + w * tile_bytes;
         if (need > lds_cu) continue;
         int b = (int)(lds_cu / need);
@@ -379,9 +400,9 @@ int srx_fused_viterbi(srx_context* h, const void* X, const int64_t* off, int64_t
     tb.Wp = base; tb.cst = cst; tb.A = A; tb.pi = pi; tb.order = nullptr;
     // one 16-row tile per model
     hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, 16, NT, RQ, H, base, cst, A, pi);
-    const int64_t groups = (U + kUttPerWave - 1) / kUttPerWave;
+    const int64_t groups = (U + UPW - 1) / UPW;
     if (h->viterbi_path == SRX_VITERBI_AUTO) {
-        // A wave stays with its 16 utterances from their first frame to their last, so the job
+        // A wave stays with its utterances from their first frame to their last, so the job
         // needs enough groups to fill the chip (two waves per SIMD), and a last round that
         // leaves most of the SIMDs idle costs more than the two-kernel path does.
         const int64_t slots = (int64_t)h->n_cu * wpb * per_cu;
@@ -392,9 +413,9 @@ int srx_fused_viterbi(srx_context* h, const void* X, const int64_t* off, int64_t
     if (blocks > (int64_t)h->n_cu * per_cu) blocks = (int64_t)h->n_cu * per_cu;
     const dim3 grid((unsigned)blocks);
     const float* Xf = (const float*)X;
-#define SRX_CASE(s_, rq, hh)                                                                     \
-    if (S == s_ && RQ == rq && H == hh) {                                                        \
-        auto kern = viterbi_fused_kernel<s_, rq, hh>;                                            \
+#define SRX_CASE(s_, rq, hh, upw)                                                                \
+    if (S == s_ && RQ == rq && H == hh && UPW == upw) {                                          \
+        auto kern = viterbi_fused_kernel<s_, rq, hh, upw>;                                       \
         SRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)lds));                                                  \
         hipLaunchKernelGGL(kern, grid, dim3(64 * wpb), lds, st, Xf, off, U, utt_model, M, D, tb, \
@@ -403,8 +424,9 @@ int srx_fused_viterbi(srx_context* h, const void* X, const int64_t* off, int64_t
         return SRX_OK;                                                                           \
     }
 #define SRX_CASES(s_)                                                                            \
-    SRX_CASE(s_, 0, 1) SRX_CASE(s_, 1, 0) SRX_CASE(s_, 1, 1) SRX_CASE(s_, 2, 0) SRX_CASE(s_, 2, 1) \
-    SRX_CASE(s_, 3, 0)
+    SRX_CASE(s_, 0, 1, 8) SRX_CASE(s_, 1, 0, 8) SRX_CASE(s_, 1, 1, 8) SRX_CASE(s_, 2, 0, 8)      \
+    SRX_CASE(s_, 2, 1, 8) SRX_CASE(s_, 3, 0, 8) SRX_CASE(s_, 0, 1, 16) SRX_CASE(s_, 1, 0, 16)    \
+    SRX_CASE(s_, 1, 1, 16) SRX_CASE(s_, 2, 0, 16) SRX_CASE(s_, 2, 1, 16) SRX_CASE(s_, 3, 0, 16)
     SRX_CASES(1) SRX_CASES(2) SRX_CASES(3) SRX_CASES(4) SRX_CASES(5) SRX_CASES(6) SRX_CASES(7) SRX_CASES(8)
 #undef SRX_CASES
 #undef SRX_CASE

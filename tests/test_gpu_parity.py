@@ -965,7 +965,7 @@ def test_viterbi_fused_kernel_matches_oracle(sra, ctx, S, D):
     A = np.triu(prms[1].A) * (np.tril(np.ones((S, S)), 1))
     prms[1] = ho.Params(np.eye(S)[0], A / A.sum(axis=1, keepdims=True), prms[1].means, prms[1].covars)
     lengths = np.array([0, 1, 2, 15, 16, 17, 33, 200, 64, 31, 1, 48, 5, 129, 16, 0, 7, 96, 32, 3, 250,
-                        18, 16, 160, 2, 80, 47, 49, 1, 100, 12, 65, 66, 15, 14, 201, 8], dtype=np.int64)
+                        18, 16, 160, 2, 80, 47, 49, 1, 100, 12, 65, 66, 15, 14, 201, 8, 300, 256, 257], dtype=np.int64)
     um = rng.integers(0, M, size=len(lengths)).astype(np.int32)
     X = rng.standard_normal((int(lengths.sum()), D)).astype(np.float32).astype(np.float64)
     bank = _bank(sra, ctx, prms)
