@@ -389,14 +389,6 @@ int srx_fused_viterbi(srx_context* h, const void* X, const int64_t* off, int64_t
     // one 16-row tile per model
     hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, 16, NT, RQ, H, base, cst, A, pi);
     const int64_t groups = (U + kUpw - 1) / kUpw;
-    if (h->viterbi_path == SRX_VITERBI_AUTO) {
-        // A wave stays with its utterances from their first frame to their last, so the job
-        // needs enough groups to fill the chip (two waves per SIMD), and a last round that
-        // leaves most of the SIMDs idle costs more than the two-kernel path does.
-        const int64_t slots = (int64_t)h->n_cu * wpb * per_cu;
-        if (groups < (int64_t)h->n_cu * 8) return SRX_EUNSUPPORTED;
-        if (groups > slots && groups * 5 < slots * 6) return SRX_EUNSUPPORTED;
-    }
     int64_t blocks = (groups + wpb - 1) / wpb;
     if (blocks > (int64_t)h->n_cu * per_cu) blocks = (int64_t)h->n_cu * per_cu;
     const dim3 grid((unsigned)blocks);

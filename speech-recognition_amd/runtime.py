@@ -77,9 +77,9 @@ class Context:
         check(lib.srx_set_option(self._h, _lib.SRX_OPT_ESTEP_PATH, code), "srx_set_option")
 
     def set_viterbi_path(self, path):
-        """Kernels of float32 Viterbi decoding for models of at most 8 states: "auto" (one fused
-        kernel for batches large enough to fill the GPU, emission + recursion kernels
-        otherwise), "fused" or "split"."""
+        """Kernels of float32 Viterbi decoding for models of at most 8 states: "auto" / "fused"
+        (one kernel, log-densities kept on the chip) or "split" (an emission kernel, then a
+        recursion kernel)."""
         code = {"auto": _lib.SRX_VITERBI_AUTO, "fused": _lib.SRX_VITERBI_FUSED,
                 "split": _lib.SRX_VITERBI_SPLIT}[path]
         check(lib.srx_set_option(self._h, _lib.SRX_OPT_VITERBI_PATH, code), "srx_set_option")
