@@ -42,25 +42,31 @@ __device__ __host__ inline unsigned bf16_rne(float f) {
 }
 
 // ------------------------------------------------------------------ GMM tables
-// Wp[tile][q RQ][part 2][g 4][row 16][4 dwords]: the 8 bf16 weights facing the
+// Wp[tile][q RQ + H][part 2][g 4][row 16][4 dwords]: the 8 bf16 weights facing the
 // slots [x0 x1 x2 x3 s0 s1 s2 s3] of features 16q+4g .. +3, hi and lo parts, in
-// the order the lanes of one operand read consume them (lane = 16 g + row).
+// the order the lanes of one operand read consume them (lane = 16 g + row).  If H, the
+// feature axis ends in a block of 8 (lane group g: features 16 RQ + 2g, +1) whose operand
+// carries hi AND lo halves, [xh0 xh1 xl0 xl1 | sh0 sh1 sl0 sl1]: the hi weights are repeated
+// in slots 2, 3 and 6, 7 and the lo weights face zeros there -- two matrix instructions for
+// that block instead of three (39 features: 8 per tile and frame block instead of 9).
 // Row m of tile t is component 4 (t & 3) + (m & 3) of state 4 (t >> 2) + (m >> 2).
 // cst[tile][row] = log2e (ln w - 0.5 (D ln 2pi + sum ln var + sum mu^2 / var)).
-__global__ void gmm_prep_kernel(srx_gmm_t gm, int RQ, unsigned* __restrict__ Wp,
+__global__ void gmm_prep_kernel(srx_gmm_t gm, int RQ, int H, unsigned* __restrict__ Wp,
                                 float* __restrict__ cst) {
     const int S = gm.n_states, MX = gm.n_mix, D = gm.n_features;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
     const int64_t n_tiles = 4 * (((int64_t)S + 3) / 4);
-    for (int64_t i = tid; i < n_tiles * 16 * RQ * 2 * 4; i += nth) {
-        const int row = i & 15, g = (i >> 4) & 3, part = (i >> 6) & 1, q = (int)((i >> 7) % RQ);
-        const int64_t tile = (i >> 7) / RQ;
+    const int QT = RQ + H;
+    for (int64_t i = tid; i < n_tiles * 16 * QT * 2 * 4; i += nth) {
+        const int row = i & 15, g = (i >> 4) & 3, part = (i >> 6) & 1, q = (int)((i >> 7) % QT);
+        const int64_t tile = (i >> 7) / QT;
         const int64_t s = 4 * (tile >> 2) + (row >> 2);
         const int m = 4 * (int)(tile & 3) + (row & 3);
         unsigned short v[8];
         for (int j = 0; j < 8; ++j) {
-            const int d = 16 * q + 4 * g + (j & 3);
+            int d = 16 * q + 4 * g + (j & 3);
+            if (q == RQ) d = ((j & 3) < 2 || part == 0) ? 16 * RQ + 2 * g + (j & 1) : D;   // half block
             float wv = 0.f;
             if (s < S && m < MX && d < D) {
                 const size_t k = ((size_t)s * MX + m) * D + d;
@@ -132,11 +138,25 @@ constexpr int kFB = 4;                 // 16-frame blocks per wave
 constexpr int kWaves = 4;              // waves per workgroup
 constexpr int kFramesPerBlock = 16 * kFB * kWaves;
 
-template <int RQ>
+// The last block of 8 features as one operand (see gmm_prep_kernel).
+__device__ __forceinline__ bf16x8 split_half_operand(unsigned h0, unsigned h1) {
+    const float x0 = __uint_as_float(h0), x1 = __uint_as_float(h1);
+    const float s0 = x0 * x0, s1 = x1 * x1;
+    const bf16x2 a = {(__bf16)(x0 - __uint_as_float(h0 & 0xffff0000u)), (__bf16)(x1 - __uint_as_float(h1 & 0xffff0000u))};
+    const bf16x2 b = {(__bf16)(s0 - __uint_as_float(__float_as_uint(s0) & 0xffff0000u)),
+                      (__bf16)(s1 - __uint_as_float(__float_as_uint(s1) & 0xffff0000u))};
+    const u32x4 fb = {__builtin_amdgcn_perm(h1, h0, 0x07060302u), __builtin_bit_cast(unsigned, a),
+                      __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u),
+                      __builtin_bit_cast(unsigned, b)};
+    return __builtin_bit_cast(bf16x8, fb);
+}
+
+template <int RQ, int H>
 __global__ __launch_bounds__(256, 2) void gmm_emission_kernel(
     const float* __restrict__ X, int64_t n_frames, int S, int D, const unsigned* __restrict__ Wp,
     const float* __restrict__ cst, float* __restrict__ out) {
-    constexpr int TILE = 16 * RQ * 2 * 4 * 4;          // dwords of one tile's weights
+    constexpr int QT = RQ + H;
+    constexpr int TILE = 16 * QT * 2 * 4 * 4;          // dwords of one tile's weights
     __shared__ __attribute__((aligned(16))) unsigned s_w[2][4 * TILE];
     __shared__ float s_c[2][64];
     __shared__ float s_res[kWaves][16][16 * kFB];       // [wave][state in group][frame]
@@ -144,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void gmm_emission_kernel(
     const int64_t f_wave = (int64_t)blockIdx.x * kFramesPerBlock + (int64_t)wv * 16 * kFB;
 
     // ---- this wave's frames as split operands, loaded once
-    bf16x8 bh[kFB][RQ], bl[kFB][RQ];
+    bf16x8 bh[kFB][RQ ? RQ : 1], bl[kFB][RQ ? RQ : 1], bb[kFB];
     {
         const int64_t f0 = f_wave < n_frames ? f_wave : 0;
         const int64_t rest = f_wave < n_frames ? (n_frames - f0) * (int64_t)D * 4 : 0;
@@ -155,13 +175,19 @@ __global__ __launch_bounds__(256, 2) void gmm_emission_kernel(
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
 #pragma unroll
-        for (int fb = 0; fb < kFB; ++fb)
+        for (int fb = 0; fb < kFB; ++fb) {
 #pragma unroll
             for (int q = 0; q < RQ; ++q) {
                 const unsigned o = (unsigned)(fb * 16 + ul) * (unsigned)D * 4u + 16u * g + 64u * q;
                 const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0);   // past the end: 0
                 split_operand(x, bh[fb][q], bl[fb][q]);
             }
+            if constexpr (H != 0) {
+                const unsigned o = (unsigned)(fb * 16 + ul) * (unsigned)D * 4u + 64u * RQ + 8u * g;
+                const auto x = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o, 0, 0);
+                bb[fb] = split_half_operand(x[0], x[1]);
+            }
+        }
     }
 
     // ---- weight stream: the workgroup copies the next four tiles (four states)
@@ -198,9 +224,9 @@ __global__ __launch_bounds__(256, 2) void gmm_emission_kernel(
         f32x4 acc[4][kFB];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            u32x4 wh[RQ], wl[RQ];
+            u32x4 wh[QT], wl[QT];
 #pragma unroll
-            for (int q = 0; q < RQ; ++q) {
+            for (int q = 0; q < QT; ++q) {
                 const unsigned* p = &s_w[buf][k * TILE + ((q * 2) * 64 + lane) * 4];
                 wh[q] = *(const u32x4*)p;
                 wl[q] = *(const u32x4*)(p + 256);
@@ -222,6 +248,15 @@ __global__ __launch_bounds__(256, 2) void gmm_emission_kernel(
 #pragma unroll
                 for (int fb = 0; fb < kFB; ++fb)
                     acc[k][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[fb][q], acc[k][fb], 0, 0, 0);
+            }
+            if constexpr (H != 0) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, wh[RQ]), al = __builtin_bit_cast(bf16x8, wl[RQ]);
+#pragma unroll
+                for (int fb = 0; fb < kFB; ++fb)
+                    acc[k][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bb[fb], acc[k][fb], 0, 0, 0);
+#pragma unroll
+                for (int fb = 0; fb < kFB; ++fb)
+                    acc[k][fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bb[fb], acc[k][fb], 0, 0, 0);
             }
         }
         // ---- log-sum-exp over this lane's 16 components of state 4Q+g; log2 units
@@ -515,23 +550,24 @@ int srx_large_gmm_emission(srx_context* h, const void* X, int dtype, int64_t n_f
                            const srx_gmm_t* gm, void* out, hipStream_t st) {
     const int S = gm->n_states, MX = gm->n_mix, D = gm->n_features;
     if (dtype == SRX_F32 && !h->exact_f32 && MX <= 16 && D <= 48) {
-        const int RQ = (D + 15) / 16;
+        const int H = (D % 16 >= 1 && D % 16 <= 8) ? 1 : 0;
+        const int RQ = H ? D / 16 : (D + 15) / 16, QT = RQ + H;
         const size_t n_tiles = 4 * (((size_t)S + 3) / 4);
-        const size_t n_wp = n_tiles * 16 * RQ * 2 * 4 * 4, n_c = n_tiles * 16;
+        const size_t n_wp = n_tiles * 16 * QT * 2 * 4 * 4, n_c = n_tiles * 16;
         unsigned* base;
         int rc = srx_ws_ensure(h, WS_PARAMS, 4 * (n_wp + n_c), (void**)&base);
         if (rc) return rc;
         float* cst = (float*)(base + n_wp);
-        hipLaunchKernelGGL(gmm_prep_kernel, dim3(256), dim3(256), 0, st, *gm, RQ, base, cst);
+        hipLaunchKernelGGL(gmm_prep_kernel, dim3(256), dim3(256), 0, st, *gm, RQ, H, base, cst);
         const unsigned grid = (unsigned)((n_frames + kFramesPerBlock - 1) / kFramesPerBlock);
         const float* Xf = (const float*)X;
         float* of = (float*)out;
-        if (RQ == 1)
-            hipLaunchKernelGGL(gmm_emission_kernel<1>, dim3(grid), dim3(256), 0, st, Xf, n_frames, S, D, base, cst, of);
-        else if (RQ == 2)
-            hipLaunchKernelGGL(gmm_emission_kernel<2>, dim3(grid), dim3(256), 0, st, Xf, n_frames, S, D, base, cst, of);
-        else
-            hipLaunchKernelGGL(gmm_emission_kernel<3>, dim3(grid), dim3(256), 0, st, Xf, n_frames, S, D, base, cst, of);
+#define SRX_CASE(rq, hh)                                                                          \
+    if (RQ == rq && H == hh)                                                                      \
+        hipLaunchKernelGGL((gmm_emission_kernel<rq, hh>), dim3(grid), dim3(256), 0, st, Xf, n_frames, \
+                           S, D, base, cst, of);
+        SRX_CASE(0, 1) SRX_CASE(1, 0) SRX_CASE(1, 1) SRX_CASE(2, 0) SRX_CASE(2, 1) SRX_CASE(3, 0)
+#undef SRX_CASE
         SRX_HIP(hipGetLastError());
         return SRX_OK;
     }

@@ -43,7 +43,8 @@ def test_single_component_is_reference_density(sra, ctx, hmm_golden, case):
         np.testing.assert_allclose(ll, g[p + "loglik"], rtol=tol, atol=tol * 10)
 
 
-@pytest.mark.parametrize("S,MX,D,T", [(5, 3, 7, 100), (40, 16, 39, 333), (33, 9, 13, 257), (7, 20, 39, 64)])
+@pytest.mark.parametrize("S,MX,D,T", [(5, 3, 7, 100), (40, 16, 39, 333), (33, 9, 13, 257), (7, 20, 39, 64),
+                                      (6, 4, 20, 50), (9, 5, 45, 70), (12, 16, 26, 90)])
 def test_mixture_density_matches_oracle(sra, ctx, S, MX, D, T):
     rng = np.random.default_rng(S * 100 + MX)
     w = rng.dirichlet(np.ones(MX), size=S)
