@@ -235,20 +235,28 @@ __global__ __launch_bounds__(256, 2) void score_mfma_kernel(
 // float32: frames are the MFMA columns here -- a wave takes 16 CONSECUTIVE frames
 // (one contiguous 16 D-float piece of X), NTC tiles of 16 state columns, and
 // writes out[frame][column].  Same split-bf16 contraction as the scoring kernel.
-template <int NTC, int RQ>
+template <int NTC, int RQ, int H>
 __global__ __launch_bounds__(256) void emission_split_kernel(
     const float* __restrict__ X, int64_t n_frames, int C, int D, int NT, SplitTables tb,
     float* __restrict__ out) {
     const int lane = threadIdx.x & 63, g = lane >> 4, ul = lane & 15;
     const int nt0 = blockIdx.y * NTC;
-    u32x4 wh[NTC][RQ], wl[NTC][RQ];
+    // (the feature axis is cut as in the scoring kernel: RQ blocks of 16 and, if H, a last
+    // block of 8 whose operand carries hi and lo halves -- a 39-feature row is read in 160
+    // bytes and takes 8 matrix instructions per tile instead of 9)
+    constexpr int QT = RQ + H;
+    struct item_t {
+        u32x4 v[RQ ? RQ : 1];
+        u32x2 h;
+    };
+    u32x4 wh[NTC][QT], wl[NTC][QT];
     f32x4 c0[NTC];
 #pragma unroll
     for (int nt = 0; nt < NTC; ++nt) {
         const bool on = nt0 + nt < NT;
 #pragma unroll
-        for (int q = 0; q < RQ; ++q) {
-            const unsigned* p = tb.Wp + ((((size_t)((on ? nt0 + nt : 0) * 16 + ul)) * RQ + q) * 2 * 4 + g) * 4;
+        for (int q = 0; q < QT; ++q) {
+            const unsigned* p = tb.Wp + ((((size_t)((on ? nt0 + nt : 0) * 16 + ul)) * QT + q) * 2 * 4 + g) * 4;
             wh[nt][q] = on ? *(const u32x4*)p : u32x4{0u, 0u, 0u, 0u};
             wl[nt][q] = on ? *(const u32x4*)(p + 16) : u32x4{0u, 0u, 0u, 0u};
         }
@@ -259,7 +267,8 @@ __global__ __launch_bounds__(256) void emission_split_kernel(
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const unsigned lane_off = (unsigned)ul * (unsigned)D * 4u + 16u * g;
-    auto load = [&](int64_t grp, u32x4 (&dst)[RQ]) {
+    const unsigned half_off = (unsigned)ul * (unsigned)D * 4u + 64u * RQ + 8u * g;
+    auto load = [&](int64_t grp, item_t& dst) {
         // descriptor over [first frame of the group, end of X): frames past the
         // end read zeros
         const int64_t f0 = grp < n_groups ? grp * 16 : 0;
@@ -272,9 +281,10 @@ __global__ __launch_bounds__(256) void emission_split_kernel(
             (void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
 #pragma unroll
         for (int q = 0; q < RQ; ++q)
-            dst[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off + 64u * q, 0, 0);
+            dst.v[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off + 64u * q, 0, 0);
+        if constexpr (H != 0) dst.h = __builtin_amdgcn_raw_buffer_load_b64(rsrc, half_off, 0, 0);
     };
-    u32x4 xa[RQ], xb[RQ];
+    item_t xa, xb;
     load(wid, xa);
     for (int64_t grp = wid; grp < n_groups; grp += n_waves) {
         load(grp + n_waves, xb);
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(256) void emission_split_kernel(
 #pragma unroll
         for (int q = 0; q < RQ; ++q) {
             bf16x8 bh, bl;
-            split_operand(xa[q], bh, bl);
+            split_operand(xa.v[q], bh, bl);
 #pragma unroll
             for (int nt = 0; nt < NTC; ++nt)
                 acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
@@ -297,6 +307,17 @@ __global__ __launch_bounds__(256) void emission_split_kernel(
             for (int nt = 0; nt < NTC; ++nt)
                 acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     __builtin_bit_cast(bf16x8, wl[nt][q]), bh, acc[nt], 0, 0, 0);
+        }
+        if constexpr (H != 0) {
+            const bf16x8 bb = split_half_operand(xa.h);
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wh[nt][RQ]), bb, acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wl[nt][RQ]), bb, acc[nt], 0, 0, 0);
         }
         const int64_t f = grp * 16 + ul;
         if (f < n_frames) {
@@ -314,8 +335,7 @@ __global__ __launch_bounds__(256) void emission_split_kernel(
                 }
             }
         }
-#pragma unroll
-        for (int q = 0; q < RQ; ++q) xa[q] = xb[q];
+        xa = xb;
     }
 }
 
@@ -547,8 +567,9 @@ int srx_mfma_emission(srx_context* h, const void* X, int64_t n_frames, const srx
     const int M = md->n_models, S = md->n_states, D = md->n_features;
     const int64_t C64 = (int64_t)M * S;
     if (h->exact_f32 || D > 48 || n_frames <= 0 || C64 > 4096) return SRX_EUNSUPPORTED;
-    const int C = (int)C64, NT = (C + 15) / 16, RQ = (D + 15) / 16;
-    const size_t n_wp = (size_t)NT * 16 * RQ * 2 * 4 * 4, n_c = (size_t)NT * 16;
+    const int H = (D % 16 >= 1 && D % 16 <= 8) ? 1 : 0;
+    const int C = (int)C64, NT = (C + 15) / 16, RQ = H ? D / 16 : (D + 15) / 16, QT = RQ + H;
+    const size_t n_wp = (size_t)NT * 16 * QT * 2 * 4 * 4, n_c = (size_t)NT * 16;
     unsigned* base;
     int rc = srx_ws_ensure(h, WS_PARAMS, 4 * (n_wp + n_c + (size_t)M * S * S + (size_t)M * S),
                            (void**)&base);
@@ -559,7 +580,7 @@ int srx_mfma_emission(srx_context* h, const void* X, int64_t n_frames, const srx
     float* pi = A + (size_t)M * S * S;
     tb.Wp = base; tb.cst = cst; tb.A = A; tb.pi = pi; tb.order = nullptr;
     // rows of the table = columns of the output: "padded states per model" = S
-    hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, S, NT, RQ, 0, base, cst, A, pi);
+    hipLaunchKernelGGL(split_prep_kernel, dim3(16), dim3(256), 0, st, *md, S, NT, RQ, H, base, cst, A, pi);
     const int NTC = NT >= 3 ? 3 : NT;
     const int chunks = (NT + NTC - 1) / NTC;
     const int64_t n_groups = (n_frames + 15) / 16;
@@ -568,15 +589,18 @@ int srx_mfma_emission(srx_context* h, const void* X, int64_t n_frames, const srx
     if (gx > cap) gx = cap;
     const dim3 grid((unsigned)gx, (unsigned)chunks);
     const float* Xf = (const float*)X;
-#define SRX_CASE(ntc, rq)                                                                    \
-    if (NTC == ntc && RQ == rq) {                                                            \
-        hipLaunchKernelGGL((emission_split_kernel<ntc, rq>), grid, dim3(256), 0, st, Xf,     \
+#define SRX_CASE(ntc, rq, hh)                                                                \
+    if (NTC == ntc && RQ == rq && H == hh) {                                                 \
+        hipLaunchKernelGGL((emission_split_kernel<ntc, rq, hh>), grid, dim3(256), 0, st, Xf, \
                            n_frames, C, D, NT, tb, out);                                     \
         SRX_HIP(hipGetLastError());                                                          \
         return SRX_OK;                                                                       \
     }
-    SRX_CASE(3, 3) SRX_CASE(3, 2) SRX_CASE(3, 1) SRX_CASE(2, 3) SRX_CASE(2, 2) SRX_CASE(2, 1)
-    SRX_CASE(1, 3) SRX_CASE(1, 2) SRX_CASE(1, 1)
+#define SRX_CASES(ntc)                                                                       \
+    SRX_CASE(ntc, 0, 1) SRX_CASE(ntc, 1, 0) SRX_CASE(ntc, 1, 1) SRX_CASE(ntc, 2, 0)          \
+    SRX_CASE(ntc, 2, 1) SRX_CASE(ntc, 3, 0)
+    SRX_CASES(3) SRX_CASES(2) SRX_CASES(1)
+#undef SRX_CASES
 #undef SRX_CASE
     return SRX_EUNSUPPORTED;
 }
