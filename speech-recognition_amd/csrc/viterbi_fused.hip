@@ -372,6 +372,9 @@ int srx_fused_viterbi(srx_context* h, const void* X, const int64_t* off, int64_t
         }
     }
     if (!wpb) return SRX_EUNSUPPORTED;
+    // (a bank whose tables leave room for fewer than two waves per SIMD -- more than about 20
+    // models of 39 features -- is better served by the two-kernel path unless asked otherwise)
+    if (h->viterbi_path == SRX_VITERBI_AUTO && wpb * per_cu < 8) return SRX_EUNSUPPORTED;
     const size_t lds = w_bytes + wpb * tile_bytes;
     const int NT = M;
     const size_t n_wp = (size_t)NT * 16 * QT * 2 * 4 * 4, n_c = (size_t)NT * 16;
