@@ -999,6 +999,270 @@ __global__ __launch_bounds__(64) void fb_lane_kernel(
     }
 }
 
+// 1, 2 or 4 floats as one register group and one memory access
+template <int V> struct LaneVec;
+template <> struct LaneVec<1> {
+    typedef float type;
+    static __device__ float get(const type& x, int) { return x; }
+    static __device__ void set(type& x, int, float v) { x = v; }
+};
+template <> struct LaneVec<2> {
+    typedef float type __attribute__((ext_vector_type(2)));
+    static __device__ float get(const type& x, int w) { return x[w]; }
+    static __device__ void set(type& x, int w, float v) { x[w] = v; }
+};
+template <> struct LaneVec<4> {
+    typedef float type __attribute__((ext_vector_type(4)));
+    static __device__ float get(const type& x, int w) { return x[w]; }
+    static __device__ void set(type& x, int w, float v) { x[w] = v; }
+};
+
+// Orders the LDS accesses of a one-wave workgroup (its lanes run in lockstep and its LDS
+// operations complete in order): no hardware barrier, and unlike __syncthreads no wait for
+// the wave's outstanding global loads and stores.
+__device__ __forceinline__ void tile_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Posteriors for models of at most 8 states, float32, one lane per utterance with
+// fb_lane_kernel's arithmetic, arranged around what its memory traffic costs.  (a) Every
+// access goes through an LDS tile of 8 frames x 64 utterances that the wave fills and
+// drains together, each utterance's piece as one contiguous run of up to 256 bytes: a
+// lane reading its own rows straight from memory touches 64 cache lines per instruction,
+// and that look-up rate, not the bytes, is what bounds fb_lane_kernel.  (b) The scaled
+// forward vectors are not kept: the forward pass leaves only the vector after every
+// eighth frame (in that frame's row of the output array, which the backward pass
+// overwrites later) and the log-probability; the backward pass recomputes the forward
+// vectors and scale factors of a tile from that checkpoint -- 104 bytes per frame
+// through memory at 8 states instead of 160, for one more forward recursion in registers.
+// gamma and loglik must be aligned to the access width (16 bytes when S is a multiple of
+// 4, 8 when even).
+template <int S>
+__global__ __launch_bounds__(64) void posteriors_lane_kernel(
+    const float* __restrict__ loglik, const int64_t* __restrict__ off, int64_t U,
+    const int32_t* __restrict__ utt_model, Tables<float> tb, float* __restrict__ gamma,
+    double* __restrict__ utt_lp) {
+    constexpr int C = 8;                                        // frames per tile
+    constexpr int V = S % 4 == 0 ? 4 : S % 2 == 0 ? 2 : 1;      // dwords per access
+    constexpr int UNITS = C * S / V;                            // accesses per utterance and tile
+    constexpr int UPI = 64 / UNITS;                             // utterances per instruction
+    constexpr int NI = (64 + UPI - 1) / UPI;                    // instructions per tile
+    constexpr int STRIDE = C * S + V;                           // floats per utterance in LDS
+    typedef typename LaneVec<V>::type Vec;
+    __shared__ __attribute__((aligned(16))) float tile[64 * STRIDE];
+    __shared__ int64_t s_f0[64];
+    __shared__ int s_T[64];
+
+    const int lane = threadIdx.x;
+    const int64_t u = (int64_t)blockIdx.x * 64 + lane;
+    const bool valid = u < U;
+    const int m = valid && utt_model ? utt_model[u] : 0;
+    const int64_t f0 = valid ? off[u] : 0;
+    const int T_len = valid ? (int)(off[u + 1] - f0) : 0;
+    s_f0[lane] = f0;
+    s_T[lane] = T_len;
+    int n_tiles = (T_len + C - 1) / C;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) n_tiles = max(n_tiles, __shfl_xor(n_tiles, o));
+    tile_sync();
+
+    float A[S][S], pi[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i)
+#pragma unroll
+        for (int j = 0; j < S; ++j) A[i][j] = tb.A[((size_t)m * S + i) * S + j];
+#pragma unroll
+    for (int j = 0; j < S; ++j) pi[j] = tb.pi[m * S + j];
+
+    // the wave's share of moving a tile: instruction i carries UPI utterances, lane
+    // (sub, unit) the unit-th access of utterance i * UPI + sub
+    const int sub = lane / UNITS, unit = lane - sub * UNITS;
+    const int fr = unit * V / S;                                // frame of the access within the tile
+    const bool mover = sub < UPI;
+    auto fetch = [&](int c, Vec (&r)[NI]) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = min(i * UPI + sub, 63);
+            const bool ok = mover && i * UPI + sub < 64 && c * C + fr < s_T[e];
+            // (pieces beyond an utterance's end read the array's first bytes instead)
+            const float* p = ok ? loglik + (s_f0[e] + (int64_t)c * C) * S + unit * V : loglik;
+            r[i] = *(const Vec*)p;
+        }
+    };
+    auto fill = [&](const Vec (&r)[NI]) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = i * UPI + sub;
+            if (mover && e < 64) *(Vec*)(tile + e * STRIDE + unit * V) = r[i];
+        }
+    };
+    auto drain = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = min(i * UPI + sub, 63);
+            const bool ok = mover && i * UPI + sub < 64 && c * C + fr < s_T[e];
+            float* p = gamma + (s_f0[e] + (int64_t)c * C) * S + unit * V;
+            if (ok) *(Vec*)p = *(const Vec*)(tile + e * STRIDE + unit * V);
+        }
+    };
+    float* my = tile + lane * STRIDE;
+    auto get_row = [&](int k, float (&row)[S]) {
+#pragma unroll
+        for (int q = 0; q < S / V; ++q) {
+            const Vec x = *(const Vec*)(my + k * S + q * V);
+#pragma unroll
+            for (int w = 0; w < V; ++w) row[q * V + w] = LaneVec<V>::get(x, w);
+        }
+    };
+    // b~ = exp(l - max l) of one frame and the maximum it was shifted by
+    auto emis = [&](const float (&row)[S], float (&b)[S]) {
+        float mx = row[0];
+#pragma unroll
+        for (int j = 1; j < S; ++j) mx = fmaxf(mx, row[j]);
+#pragma unroll
+        for (int j = 0; j < S; ++j) b[j] = __expf(row[j] - mx);
+        return mx;
+    };
+    // one forward step on alpha; returns 1 / c_t, leaves c_t in c_out
+    float alpha[S];
+    auto fwd = [&](bool first, const float (&b)[S], float& c_out) {
+        float a[S];
+        if (first) {
+#pragma unroll
+            for (int j = 0; j < S; ++j) a[j] = pi[j] * b[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < S; ++i) acc += alpha[i] * A[i][j];
+                a[j] = acc * b[j];
+            }
+        }
+        float c = 0.f;
+#pragma unroll
+        for (int j = 0; j < S; ++j) c += a[j];
+        c_out = c;
+        const float ci = __builtin_amdgcn_rcpf(c);
+#pragma unroll
+        for (int j = 0; j < S; ++j) alpha[j] = a[j] * ci;
+        return ci;
+    };
+
+    // ---- forward: log-probability and a checkpoint per tile
+    Vec R[NI];
+    double lp = 0.0;
+    float lpf = 0.f;                                  // folded into lp after frames 4, 8, ...
+    if (n_tiles > 0) fetch(0, R);
+    for (int c = 0; c < n_tiles; ++c) {
+        fill(R);
+        tile_sync();
+        if (c + 1 < n_tiles) fetch(c + 1, R);
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int t = c * C + k;
+            if (t < T_len) {
+                float row[S], b[S], cs;
+                get_row(k, row);
+                const float mx = emis(row, b);
+                fwd(c == 0 && k == 0, b, cs);
+                lpf += mx + __logf(cs);
+                if ((k & 3) == 0 && t > 0) {
+                    lp += (double)lpf;
+                    lpf = 0.f;
+                }
+            }
+        }
+        if ((c + 1) * C < T_len) {
+            float* o = gamma + (f0 + (int64_t)c * C + C - 1) * S;
+#pragma unroll
+            for (int q = 0; q < S / V; ++q) {
+                Vec x;
+#pragma unroll
+                for (int w = 0; w < V; ++w) LaneVec<V>::set(x, w, alpha[q * V + w]);
+                *(Vec*)(o + q * V) = x;
+            }
+        }
+        tile_sync();                              // the tile is refilled next
+    }
+    lp += (double)lpf;
+    if (valid && utt_lp) utt_lp[u] = lp;
+
+    // ---- backward: tiles from the last to the first; bb = b~_{t+1} beta_{t+1}
+    float bb[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) bb[j] = 0.f;
+    Vec ck[S / V], ck_n[S / V];
+    auto checkpoint = [&](int c, Vec (&r)[S / V]) {
+        const float* p = c > 0 && c * C < T_len ? gamma + (f0 + (int64_t)c * C - 1) * S : gamma;
+#pragma unroll
+        for (int q = 0; q < S / V; ++q) r[q] = *(const Vec*)(p + q * V);
+    };
+    if (n_tiles > 0) {
+        fetch(n_tiles - 1, R);
+        checkpoint(n_tiles - 1, ck);
+    }
+    for (int c = n_tiles - 1; c >= 0; --c) {
+        fill(R);
+        tile_sync();
+        if (c > 0) {
+            fetch(c - 1, R);
+            checkpoint(c - 1, ck_n);
+        }
+        // the forward vectors, scale factors and b~ of the tile's frames again
+        float al[C][S], bq[C][S], cinv[C];
+#pragma unroll
+        for (int j = 0; j < S; ++j) alpha[j] = LaneVec<V>::get(ck[j / V], j % V);
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int t = c * C + k;
+            if (t < T_len) {
+                float row[S], cs;
+                get_row(k, row);
+                emis(row, bq[k]);
+                cinv[k] = fwd(c == 0 && k == 0, bq[k], cs);
+#pragma unroll
+                for (int j = 0; j < S; ++j) al[k][j] = alpha[j];
+            }
+        }
+#pragma unroll
+        for (int k = C - 1; k >= 0; --k) {
+            const int t = c * C + k;
+            if (t < T_len) {
+                const bool last = t == T_len - 1;
+                float g[S], gs = 0.f, beta[S];
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < S; ++j) acc += A[i][j] * bb[j];
+                    beta[i] = last ? cinv[k] : acc * cinv[k];
+                    g[i] = al[k][i] * beta[i];
+                    gs += g[i];
+                }
+                if (gs == 0.f) gs = 1.f;              // utils.normalize: zero rows divide by 1
+                const float gi = __builtin_amdgcn_rcpf(gs);
+#pragma unroll
+                for (int q = 0; q < S / V; ++q) {
+                    Vec x;
+#pragma unroll
+                    for (int w = 0; w < V; ++w) LaneVec<V>::set(x, w, g[q * V + w] * gi);
+                    *(Vec*)(my + k * S + q * V) = x;
+                }
+#pragma unroll
+                for (int i = 0; i < S; ++i) bb[i] = bq[k][i] * beta[i];
+            }
+        }
+        tile_sync();
+        drain(c);
+        tile_sync();
+#pragma unroll
+        for (int q = 0; q < S / V; ++q) ck[q] = ck_n[q];
+    }
+}
+
 // Float64 E-step of small jobs.  A pass over all frames first replaces every row of
 // log-densities by b~ = exp(l - max l) and keeps the maxima (the software float64
 // exponentials run in parallel there instead of inside the recursion); then one lane per
@@ -1390,6 +1654,12 @@ int viterbi_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int6
     return SRX_OK;
 }
 
+#ifdef SRX_POSTERIORS_DIRECT
+constexpr bool kPosteriorsTiled = false;     // (measurement builds: fb_lane_kernel instead)
+#else
+constexpr bool kPosteriorsTiled = true;
+#endif
+
 // Posteriors of every frame under its utterance's model: the forward-backward
 // chain with the caller's array as the lattice, no statistics.
 template <typename T>
@@ -1422,6 +1692,18 @@ int posteriors_t(srx_context* h, const void* X, const int64_t* off, int64_t U, i
         hipLaunchKernelGGL(emission_kernel<T>, dim3(grid_for(h, U, 1)), dim3(kBlock), 0, st,
                            (const T*)X, off, U, utt_model, 0, M, S, D, tb, ll);
     if constexpr (std::is_same<T, float>::value) {
+        if (S <= 8 && ((uintptr_t)gamma & 15) == 0 && kPosteriorsTiled) {
+            const dim3 grid((unsigned)((U + 63) / 64));
+#define SRX_CASE(s_)                                                                       \
+    if (S == s_)                                                                           \
+        hipLaunchKernelGGL((posteriors_lane_kernel<s_>), grid, dim3(64), 0, st,            \
+                           (const float*)ll, off, U, utt_model, tb, (float*)gamma, lp);
+            SRX_CASE(1) SRX_CASE(2) SRX_CASE(3) SRX_CASE(4) SRX_CASE(5) SRX_CASE(6) SRX_CASE(7)
+            SRX_CASE(8)
+#undef SRX_CASE
+            SRX_HIP(hipGetLastError());
+            return SRX_OK;
+        }
         if (S <= 8) {
             const int bs = 64;
             const dim3 grid((unsigned)((U + bs - 1) / bs));

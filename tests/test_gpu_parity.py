@@ -488,6 +488,31 @@ def test_posteriors_ragged_multi_model(sra, ctx, S, D, dtype, tol):
         np.testing.assert_allclose(gam[off[u]:off[u + 1]], rg, rtol=0, atol=tol)
 
 
+@pytest.mark.parametrize("S", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_posteriors_small_models_every_state_count(sra, ctx, S):
+    """float32 posteriors of models of 1 to 8 states (the lane-per-utterance kernel that moves
+    its data in tiles of 8 frames): several waves, the last one partly filled, lengths on
+    both sides of every multiple of 8, empty utterances, against the oracle."""
+    rng = np.random.default_rng(40 + S)
+    M, D = 3, 6
+    prms = [ho.random_params(rng, S, D) for _ in range(M)]
+    lengths = np.concatenate([[0, 1, 2, 7, 8, 9, 15, 16, 17, 23, 24, 25, 64, 65, 0],
+                              rng.integers(0, 70, size=135)])
+    um = rng.integers(0, M, size=len(lengths)).astype(np.int32)
+    X = rng.standard_normal((lengths.sum(), D))
+    bank = _bank(sra, ctx, prms)
+    lp, gam = bank.posteriors(sra.Ragged(ctx, X, lengths, dtype="float32"), um)
+    lp, gam = lp.cpu().numpy(), gam.cpu().numpy().astype(np.float64)
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    for u, n in enumerate(lengths):
+        if n == 0:
+            assert lp[u] == 0.0
+            continue
+        rl, rg = ho.score_posteriors(prms[um[u]], X[off[u]:off[u + 1]], [n], loops=False)
+        assert abs(lp[u] - rl[0]) <= 2e-5 * abs(rl[0])
+        np.testing.assert_allclose(gam[off[u]:off[u + 1]], rg, rtol=0, atol=2e-5)
+
+
 def test_model_class_posterior_surface(sra, hmm_golden, posteriors_golden):
     """score_scaling / score_samples / predict_proba / predict / sample of the
     model class."""
