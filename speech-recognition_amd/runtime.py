@@ -297,12 +297,19 @@ class HMMBank:
                               self.ctx.stream_ptr()), "srx_viterbi")
         return lp, path
 
-    def posteriors(self, data, utt_model=None):
+    def posteriors(self, data, utt_model=None, out=None):
         """(per-utterance log-probability (U,) float64, posteriors (n_frames, S) in
         the data's dtype): score_scaling with compute_posteriors=True,
-        my_hmmlearn/hmm.py:308-328, each utterance under its own model."""
+        my_hmmlearn/hmm.py:308-328, each utterance under its own model.  out: a contiguous
+        (n_frames, S) tensor of the data's dtype to write the posteriors into."""
         self._check(data)
-        gamma = torch.empty((data.n_frames, self.S), dtype=data.X.dtype, device=self.ctx.device)
+        if out is None:
+            out = torch.empty((data.n_frames, self.S), dtype=data.X.dtype, device=self.ctx.device)
+        if out.shape != (data.n_frames, self.S) or out.dtype != data.X.dtype or \
+                not out.is_contiguous() or out.device != data.X.device:
+            raise ValueError("out must be a contiguous (n_frames, n_states) tensor of the data's "
+                             "dtype on the data's device")
+        gamma = out
         lp = torch.empty((data.U,), dtype=torch.float64, device=self.ctx.device)
         um = self._utt_model(data, utt_model)
         check(lib.srx_posteriors(self.ctx.handle, ptr(data.X), data.code, ptr(data.offsets), data.U,

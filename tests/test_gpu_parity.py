@@ -513,6 +513,28 @@ def test_posteriors_small_models_every_state_count(sra, ctx, S):
         np.testing.assert_allclose(gam[off[u]:off[u + 1]], rg, rtol=0, atol=2e-5)
 
 
+def test_posteriors_into_an_unaligned_array(sra, ctx):
+    """The tiled kernel moves 16 bytes at a time; an output array that is only 4-byte aligned
+    takes the kernel that reads and writes row by row.  Same posteriors either way."""
+    import torch
+    rng = np.random.default_rng(77)
+    S, D = 8, 9
+    prms = [ho.random_params(rng, S, D) for _ in range(2)]
+    lengths = rng.integers(0, 60, size=90)
+    um = rng.integers(0, 2, size=len(lengths)).astype(np.int32)
+    X = rng.standard_normal((lengths.sum(), D))
+    bank = _bank(sra, ctx, prms)
+    data = sra.Ragged(ctx, X, lengths, dtype="float32")
+    lp0, g0 = bank.posteriors(data, um)
+    flat = torch.zeros(data.n_frames * S + 1, dtype=torch.float32, device=g0.device)
+    out = flat[1:].view(data.n_frames, S)
+    assert out.data_ptr() % 16 == 4
+    lp1, g1 = bank.posteriors(data, um, out=out)
+    assert g1.data_ptr() == out.data_ptr() and float(flat[0]) == 0.0
+    np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(lp1.cpu().numpy(), lp0.cpu().numpy(), rtol=1e-6)
+
+
 def test_model_class_posterior_surface(sra, hmm_golden, posteriors_golden):
     """score_scaling / score_samples / predict_proba / predict / sample of the
     model class."""
