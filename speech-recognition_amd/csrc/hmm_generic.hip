@@ -1005,16 +1005,36 @@ template <> struct LaneVec<1> {
     typedef float type;
     static __device__ float get(const type& x, int) { return x; }
     static __device__ void set(type& x, int, float v) { x = v; }
+    static __device__ type load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    }
+    static __device__ void store(type x, __amdgpu_buffer_rsrc_t r, unsigned off) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, off, 0, 0);
+    }
 };
 template <> struct LaneVec<2> {
     typedef float type __attribute__((ext_vector_type(2)));
+    typedef unsigned bits __attribute__((ext_vector_type(2)));
     static __device__ float get(const type& x, int w) { return x[w]; }
     static __device__ void set(type& x, int w, float v) { x[w] = v; }
+    static __device__ type load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        return (type)__builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    }
+    static __device__ void store(type x, __amdgpu_buffer_rsrc_t r, unsigned off) {
+        __builtin_amdgcn_raw_buffer_store_b64((bits)x, r, off, 0, 0);
+    }
 };
 template <> struct LaneVec<4> {
     typedef float type __attribute__((ext_vector_type(4)));
+    typedef unsigned bits __attribute__((ext_vector_type(4)));
     static __device__ float get(const type& x, int w) { return x[w]; }
     static __device__ void set(type& x, int w, float v) { x[w] = v; }
+    static __device__ type load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        return (type)__builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    }
+    static __device__ void store(type x, __amdgpu_buffer_rsrc_t r, unsigned off) {
+        __builtin_amdgcn_raw_buffer_store_b128((bits)x, r, off, 0, 0);
+    }
 };
 
 // Orders the LDS accesses of a one-wave workgroup (its lanes run in lockstep and its LDS
@@ -1028,23 +1048,25 @@ __device__ __forceinline__ void tile_sync() {
 
 // Posteriors for models of at most 8 states, float32, one lane per utterance with
 // fb_lane_kernel's arithmetic, arranged around what its memory traffic costs.  (a) Every
-// access goes through an LDS tile of 8 frames x 64 utterances that the wave fills and
-// drains together, each utterance's piece as one contiguous run of up to 256 bytes: a
-// lane reading its own rows straight from memory touches 64 cache lines per instruction,
-// and that look-up rate, not the bytes, is what bounds fb_lane_kernel.  (b) The scaled
-// forward vectors are not kept: the forward pass leaves only the vector after every
-// eighth frame (in that frame's row of the output array, which the backward pass
-// overwrites later) and the log-probability; the backward pass recomputes the forward
-// vectors and scale factors of a tile from that checkpoint -- 104 bytes per frame
-// through memory at 8 states instead of 160, for one more forward recursion in registers.
-// gamma and loglik must be aligned to the access width (16 bytes when S is a multiple of
-// 4, 8 when even).
+// access goes through an LDS tile of C = 8 (16 for S <= 4) frames x 64 utterances that the
+// wave fills and drains together, each utterance's piece as one contiguous run of up to
+// 256 bytes: a lane reading its own rows straight from memory touches 64 cache lines per
+// instruction, and that look-up rate, not the bytes, is what bounds fb_lane_kernel.
+// (b) The scaled forward vectors are not kept: the forward pass leaves only the vector
+// after the last frame of every tile (in that frame's row of the output array, which the
+// backward pass overwrites later) and the log-probability; the backward pass recomputes
+// the forward vectors and scale factors of a tile from that checkpoint -- 104 bytes per
+// frame through memory at 8 states instead of 160, for one more forward recursion in
+// registers.  gamma and loglik must be aligned to the access width (16 bytes when S is a
+// multiple of 4, 8 when even) and shorter than 4 GiB (n_bytes = their size).
 template <int S>
 __global__ __launch_bounds__(64) void posteriors_lane_kernel(
     const float* __restrict__ loglik, const int64_t* __restrict__ off, int64_t U,
     const int32_t* __restrict__ utt_model, Tables<float> tb, float* __restrict__ gamma,
-    double* __restrict__ utt_lp) {
-    constexpr int C = 8;                                        // frames per tile
+    double* __restrict__ utt_lp, unsigned n_bytes) {
+    // frames per tile: 16 for the smallest models, whose recursion over 8 frames is shorter
+    // than the memory round trip of the tile fetched meanwhile
+    constexpr int C = S <= 4 ? 16 : 8;
     constexpr int V = S % 4 == 0 ? 4 : S % 2 == 0 ? 2 : 1;      // dwords per access
     constexpr int UNITS = C * S / V;                            // accesses per utterance and tile
     constexpr int UPI = 64 / UNITS;                             // utterances per instruction
@@ -1052,8 +1074,7 @@ __global__ __launch_bounds__(64) void posteriors_lane_kernel(
     constexpr int STRIDE = C * S + V;                           // floats per utterance in LDS
     typedef typename LaneVec<V>::type Vec;
     __shared__ __attribute__((aligned(16))) float tile[64 * STRIDE];
-    __shared__ int64_t s_f0[64];
-    __shared__ int s_T[64];
+    __shared__ uint2 s_span[64];               // an utterance's first byte in the arrays, and its end
 
     const int lane = threadIdx.x;
     const int64_t u = (int64_t)blockIdx.x * 64 + lane;
@@ -1061,8 +1082,7 @@ __global__ __launch_bounds__(64) void posteriors_lane_kernel(
     const int m = valid && utt_model ? utt_model[u] : 0;
     const int64_t f0 = valid ? off[u] : 0;
     const int T_len = valid ? (int)(off[u + 1] - f0) : 0;
-    s_f0[lane] = f0;
-    s_T[lane] = T_len;
+    s_span[lane] = make_uint2((unsigned)(f0 * S * 4), (unsigned)((f0 + T_len) * S * 4));
     int n_tiles = (T_len + C - 1) / C;
 #pragma unroll
     for (int o = 32; o; o >>= 1) n_tiles = max(n_tiles, __shfl_xor(n_tiles, o));
@@ -1076,35 +1096,44 @@ __global__ __launch_bounds__(64) void posteriors_lane_kernel(
 #pragma unroll
     for (int j = 0; j < S; ++j) pi[j] = tb.pi[m * S + j];
 
-    // the wave's share of moving a tile: instruction i carries UPI utterances, lane
-    // (sub, unit) the unit-th access of utterance i * UPI + sub
+    // The wave's share of moving a tile: instruction i carries UPI utterances, lane (sub, unit)
+    // the unit-th access of utterance i * UPI + sub (UPI is a power of two for every S: the
+    // instructions cover the 64 utterances exactly).  Both arrays are addressed as buffers of
+    // n_bytes with 32-bit offsets, so an access past the end of the arrays returns zeros or
+    // is dropped: a tile may be fetched beyond an utterance's end (into the next utterance's
+    // rows, which the lane never uses), only the stores check the utterance's end.
+    static_assert(NI * UPI == 64, "tile instructions must cover the wave's utterances");
+    const __amdgpu_buffer_rsrc_t r_ll =
+        __builtin_amdgcn_make_buffer_rsrc((void*)loglik, 0, n_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_g = __builtin_amdgcn_make_buffer_rsrc((void*)gamma, 0, n_bytes, 0x00020000);
     const int sub = lane / UNITS, unit = lane - sub * UNITS;
-    const int fr = unit * V / S;                                // frame of the access within the tile
     const bool mover = sub < UPI;
+    const unsigned lane_off = (unsigned)unit * V * 4;
     auto fetch = [&](int c, Vec (&r)[NI]) {
+        const unsigned tile_off = (unsigned)c * (C * S * 4) + lane_off;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int e = min(i * UPI + sub, 63);
-            const bool ok = mover && i * UPI + sub < 64 && c * C + fr < s_T[e];
-            // (pieces beyond an utterance's end read the array's first bytes instead)
-            const float* p = ok ? loglik + (s_f0[e] + (int64_t)c * C) * S + unit * V : loglik;
-            r[i] = *(const Vec*)p;
+            unsigned o = s_span[(i * UPI + sub) & 63].x + tile_off;
+            if constexpr (UPI * UNITS < 64) o = mover ? o : 0xffffffffu;
+            r[i] = LaneVec<V>::load(r_ll, o);
         }
     };
     auto fill = [&](const Vec (&r)[NI]) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int e = i * UPI + sub;
-            if (mover && e < 64) *(Vec*)(tile + e * STRIDE + unit * V) = r[i];
+            if (mover) *(Vec*)(tile + e * STRIDE + unit * V) = r[i];
         }
     };
     auto drain = [&](int c) {
+        const unsigned tile_off = (unsigned)c * (C * S * 4) + lane_off;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int e = min(i * UPI + sub, 63);
-            const bool ok = mover && i * UPI + sub < 64 && c * C + fr < s_T[e];
-            float* p = gamma + (s_f0[e] + (int64_t)c * C) * S + unit * V;
-            if (ok) *(Vec*)p = *(const Vec*)(tile + e * STRIDE + unit * V);
+            const int e = (i * UPI + sub) & 63;
+            const uint2 sp = s_span[e];
+            const unsigned o = sp.x + tile_off;
+            const Vec x = *(const Vec*)(tile + e * STRIDE + unit * V);
+            LaneVec<V>::store(x, r_g, mover && o < sp.y ? o : 0xffffffffu);
         }
     };
     float* my = tile + lane * STRIDE;
@@ -1692,12 +1721,15 @@ int posteriors_t(srx_context* h, const void* X, const int64_t* off, int64_t U, i
         hipLaunchKernelGGL(emission_kernel<T>, dim3(grid_for(h, U, 1)), dim3(kBlock), 0, st,
                            (const T*)X, off, U, utt_model, 0, M, S, D, tb, ll);
     if constexpr (std::is_same<T, float>::value) {
-        if (S <= 8 && ((uintptr_t)gamma & 15) == 0 && kPosteriorsTiled) {
+        // (the tiled kernel addresses both arrays with 32-bit byte offsets)
+        if (S <= 8 && ((uintptr_t)gamma & 15) == 0 && (uint64_t)n_frames * S * 4 < (1ull << 32) &&
+            kPosteriorsTiled) {
             const dim3 grid((unsigned)((U + 63) / 64));
 #define SRX_CASE(s_)                                                                       \
     if (S == s_)                                                                           \
         hipLaunchKernelGGL((posteriors_lane_kernel<s_>), grid, dim3(64), 0, st,            \
-                           (const float*)ll, off, U, utt_model, tb, (float*)gamma, lp);
+                           (const float*)ll, off, U, utt_model, tb, (float*)gamma, lp,        \
+                           (unsigned)((uint64_t)n_frames * S * 4));
             SRX_CASE(1) SRX_CASE(2) SRX_CASE(3) SRX_CASE(4) SRX_CASE(5) SRX_CASE(6) SRX_CASE(7)
             SRX_CASE(8)
 #undef SRX_CASE
