@@ -95,7 +95,7 @@ __global__ void prep_kernel(srx_models_t md, T* mu, T* hinv, T* cst, T* A, T* pi
 // One workgroup per utterance (grid-stride).  sel < 0: all models, columns
 // m*S+s; otherwise only the utterance's own model (utt_model or model 0).
 template <typename T>
-__global__ void emission_kernel(const T* __restrict__ X, const int64_t* __restrict__ off,
+__global__ __launch_bounds__(kBlock) void emission_kernel(const T* __restrict__ X, const int64_t* __restrict__ off,
                                 int64_t U, const int32_t* __restrict__ utt_model, int all_models,
                                 int M, int S, int D, Tables<T> tb, T* __restrict__ out) {
     const int NC = all_models ? M * S : S;
@@ -200,7 +200,7 @@ template <> __device__ __forceinline__ double neg_inf<double>() { return -(doubl
 
 // Scaled forward over one chain per sub-wave.  loglik row stride is NC.
 template <typename T, int SP>
-__global__ void score_chain_kernel(const T* __restrict__ loglik, const int64_t* __restrict__ off,
+__global__ __launch_bounds__(kBlock) void score_chain_kernel(const T* __restrict__ loglik, const int64_t* __restrict__ off,
                                    int64_t U, int M, int S, Tables<T> tb,
                                    double* __restrict__ out) {
     const int j = threadIdx.x % SP;
@@ -250,7 +250,7 @@ __global__ void score_chain_kernel(const T* __restrict__ loglik, const int64_t* 
 // With partial == NULL only the posteriors and utt_lp[u] (per-utterance
 // log-probability, may itself be NULL otherwise) are produced.
 template <typename T, int SP>
-__global__ void fb_chain_kernel(T* __restrict__ loglik, const int64_t* __restrict__ off,
+__global__ __launch_bounds__(kBlock) void fb_chain_kernel(T* __restrict__ loglik, const int64_t* __restrict__ off,
                                 int64_t U, const int32_t* __restrict__ utt_model,
                                 const int64_t* __restrict__ utt_order, int M, int S,
                                 Tables<T> tb, T* __restrict__ lat, T* __restrict__ scale,
@@ -371,7 +371,7 @@ __global__ void fb_chain_kernel(T* __restrict__ loglik, const int64_t* __restric
 // model does not change, then adds them to its own slice of `partial`
 // [gridDim][M][S + 2 S D].
 template <typename T, int SLOTS>
-__global__ void obs_stats_kernel(const T* __restrict__ X, const T* __restrict__ gamma,
+__global__ __launch_bounds__(kBlock) void obs_stats_kernel(const T* __restrict__ X, const T* __restrict__ gamma,
                                  const int64_t* __restrict__ off, int64_t U,
                                  const int32_t* __restrict__ utt_model,
                                  const int64_t* __restrict__ utt_order, int M, int S, int D,
@@ -578,7 +578,7 @@ __global__ void reduce_stats_kernel(const double* __restrict__ part_fb, int n_fb
 }
 
 template <typename T, int SP>
-__global__ void viterbi_chain_kernel(const T* __restrict__ loglik,
+__global__ __launch_bounds__(kBlock) void viterbi_chain_kernel(const T* __restrict__ loglik,
                                      const int64_t* __restrict__ off, int64_t U,
                                      const int32_t* __restrict__ utt_model, int S, Tables<T> tb,
                                      uint8_t* __restrict__ bp, int32_t* __restrict__ path,
