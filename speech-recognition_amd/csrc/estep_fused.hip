@@ -3,8 +3,10 @@
 // One wave processes 16 utterances of ONE model at a time, step by step:
 //   forward   emission contraction -> b~_t, then
 //             alpha_t = (A^T alpha_{t-1}) * b~_t / c_t with the 16x16 mat-vec
-//             as 4 MFMAs; alpha_t and 1/c_t are spilled ([frames,16] floats).
-//   backward  emission again (cheaper than spilling it), beta_t = c_t A (b~ beta)_{t+1}
+//             as 4 MFMAs; alpha_t is spilled ([frames,16] floats).
+//   backward  b~_t / c_t = alpha_t / (A^T alpha_{t-1}) from the spilled lattice (4 MFMAs and
+//             four divisions: the factor the forward pass multiplied by, without contracting
+//             the frame with the model again), beta_t = A (b~ beta / c)_{t+1}
 //             as 4 MFMAs, gamma_t, and two accumulating products whose
 //             contraction index is the utterance:
 //                 G   += alpha_t   (b~ beta)_{t+1}^T      (16 x 16)     4 MFMAs
@@ -22,9 +24,9 @@
 // Memory.  The feature axis is cut into RQ blocks of 16 plus, if H, one of 8.
 // Lane group g reads features 16q+4g..+3 of a block with one 16-byte raw buffer
 // load (8q'+2g..+1 with an 8-byte load in the half block); loads are range-
-// checked and rows are only 4-byte aligned.  Frames,
-// and in the backward pass the spilled alpha and scale, are requested PF steps
-// ahead in a branch-free loop so the waits stay counted.
+// checked and rows are only 4-byte aligned.  Frames are
+// requested PF steps ahead (backward pass: two, and the spilled alpha three) in a
+// branch-free loop so the waits stay counted.
 // Spilled lattice.  A batch owns as many lattice rows as its utterances have
 // frames, starting at the exclusive prefix sum of the batch totals (a small scan
 // kernel).  Inside, rows are time-major and dense: step t occupies the next
@@ -52,6 +54,14 @@ constexpr int kReplicas = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int PF = 3;
 constexpr float kNegBig = -1.0e30f;
+// The backward pass takes b~_t / c_t from the lattice (alpha_t / (A^T alpha_{t-1}), see the
+// kernel) instead of contracting the frame with the model again.  (SRX_ESTEP_REEMIT: the
+// kernel that recomputes the emission, for measurements.)
+#ifdef SRX_ESTEP_REEMIT
+constexpr bool kRatio = false;
+#else
+constexpr bool kRatio = true;
+#endif
 constexpr double kLn2 = 0.6931471805599453;
 
 __host__ __device__ inline int sigma(int row) { return 4 * (row & 3) + (row >> 2); }
@@ -371,8 +381,9 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                 rows_done += __builtin_popcount(lm);
                                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, alpha), rsrc_lat,
                                                        live ? row * 64u + 16u * g : kDrop, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ci), rsrc_sc,
-                                                      live && g == 0 ? row * 4u : kDrop, 0, 0);
+                if constexpr (!kRatio)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ci), rsrc_sc,
+                                                          live && g == 0 ? row * 4u : kDrop, 0, 0);
             };
             if (Tmax > 0) {
                 fwd(std::true_type{}, 0, xq[0]);
@@ -396,24 +407,32 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
             f32x4 O[NTX];
 #pragma unroll
             for (int nt = 0; nt < NTX; ++nt) O[nt] = bb;
-            f32x4 alq[2];
-            float ciq[2];
-            // Loads are issued in strictly descending t, so one running row counter
-            // serves them.
-            auto loadb = [&](int t, frame_t& xd, f32x4& ad, float& cd) {
+            // Step t needs alpha_t and alpha_{t-1}: the lattice rows are requested three steps
+            // ahead into four slots (slot of step t = (Tmax - 1 - t) & 3), the frames two steps
+            // ahead into two.  Lattice loads are issued in strictly descending t, so one
+            // running row counter serves them.
+            f32x4 alq[4];
+            float ciq[4];
+            auto loada = [&](int t, f32x4& ad, float& cd) {
                 const unsigned lm = (unsigned)__ballot(t >= 0 && t < T) & 0xFFFFu;
                 rows_done -= __builtin_popcount(lm);
                 const unsigned row = rows_done + __builtin_popcount(lm & below);
-                loadx(t, xd);
                 ad = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                    rsrc_lat, row * 64u + 16u * g, 0, 0));
-                cd = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_sc, row * 4u, 0, 0));
+                if constexpr (!kRatio)
+                    cd = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_sc, row * 4u, 0, 0));
             };
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                loadb(Tmax - 1 - i, xq[i], alq[i], ciq[i]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            // (issued in the order the loop issues them, so that its waits stay counted)
+            loada(Tmax - 1, alq[0], ciq[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            loadx(Tmax - 1, xq[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            loada(Tmax - 2, alq[1], ciq[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            loadx(Tmax - 2, xq[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            loada(Tmax - 3, alq[2], ciq[2]);
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (!POST) {
                 // the first consume reads buffer 1: start it from zeros
                 for (int i = lane; i < TILE / 4; i += 64) ((f32x4*)(tiles + TILE))[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -457,21 +476,41 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                     }
                 }
             };
-            auto produce = [&](int t, float* tl, const frame_t& xc, const f32x4& al_in, float ci_in) {
+            // al_prev: alpha of step t - 1 (kRatio; anything at t = 0, where b~ is not used)
+            auto produce = [&](int t, float* tl, const frame_t& xc, const f32x4& al_in, float ci_in,
+                               const f32x4& al_prev) {
                 float* t_gam = tl;
                 float* t_alp = tl + 256;
                 float* t_bb = tl + 512;
                 float* t_x = tl + 768;
                 const bool live = t < T && t >= 0;
-                const f32x4 ll = emission(xc);
-                const float mx = max16(ll);
-                f32x4 b;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) b[r] = __builtin_amdgcn_exp2f(ll[r] - mx);
                 const f32x4 al = live ? al_in : f32x4{0.f, 0.f, 0.f, 0.f};
-                const float ci = live ? ci_in : 0.f;
-                f32x4 beta = matvec(aop, bb) * ci;
-                if (t == T - 1) beta = f32x4{ci, ci, ci, ci};
+                f32x4 b, beta;
+                if constexpr (kRatio) {
+                    // The forward pass formed alpha_t = (A^T alpha_{t-1}) b~_t / c_t, so the factor
+                    // the backward recursion needs, b~_t / c_t, is alpha_t over that prediction:
+                    // one 16 x 16 mat-vec and four divisions instead of the emission contraction
+                    // and its exponentials.  A state the prediction gives no mass has alpha = 0
+                    // and b~ beta = 0 either way.  A prediction below 1e-30 counts as none (the
+                    // hardware reciprocal of a subnormal is infinite, and infinity times a zero
+                    // alpha or a zero of A would be a NaN two instructions later): what such a
+                    // state could add to any posterior of step t - 1 is bounded by that 1e-30.
+                    // beta here is beta_t without its 1 / c_t.
+                    const f32x4 pred = matvec(atop, al_prev);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        b[r] = pred[r] > 1e-30f ? al[r] * __builtin_amdgcn_rcpf(pred[r]) : 0.f;
+                    beta = matvec(aop, bb);
+                    if (t == T - 1) beta = f32x4{1.f, 1.f, 1.f, 1.f};
+                } else {
+                    const f32x4 ll = emission(xc);
+                    const float mx = max16(ll);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b[r] = __builtin_amdgcn_exp2f(ll[r] - mx);
+                    const float ci = live ? ci_in : 0.f;
+                    beta = matvec(aop, bb) * ci;
+                    if (t == T - 1) beta = f32x4{ci, ci, ci, ci};
+                }
                 f32x4 gam = al * beta;
                 float gs = sum16(gam);
                 if (gs == 0.f) gs = 1.f;          // utils.normalize: zero rows divide by 1
@@ -531,16 +570,17 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                 }
             };
             // (the walk is cut into runs of kFlushSteps steps with one flush after each)
-            constexpr int kFlushSteps = 512;
+            constexpr int kFlushSteps = 512;                 // (a multiple of 4: the slots keep their steps)
             for (int hi = Tmax - 1; hi >= 0; hi -= kFlushSteps) {
                 const int lo = hi >= kFlushSteps ? hi - kFlushSteps + 1 : 0;
-                for (int t0 = hi; t0 >= lo; t0 -= 2) {
+                for (int t0 = hi; t0 >= lo; t0 -= 4) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int t = t0 - i;             // t = -1: a dead step, writes zero tiles
-                        if constexpr (!POST) consume(tiles + TILE * (i ^ 1));
-                        produce(t, tiles + TILE * i, xq[i], alq[i], ciq[i]);
-                        loadb(t - 2, xq[i], alq[i], ciq[i]);
+                    for (int i = 0; i < 4; ++i) {
+                        const int t = t0 - i;             // t < 0: a dead step, writes zero tiles
+                        if constexpr (!POST) consume(tiles + TILE * ((i & 1) ^ 1));
+                        produce(t, tiles + TILE * (i & 1), xq[i & 1], alq[i], ciq[i], alq[(i + 1) & 3]);
+                        loadx(t - 2, xq[i & 1]);
+                        loada(t - 3, alq[(i + 3) & 3], ciq[(i + 3) & 3]);
                         if constexpr (!POST) wave_sync();
                     }
                 }

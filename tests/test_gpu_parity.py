@@ -823,6 +823,60 @@ def test_offset_features_stay_within_the_expanded_form_bound(sra, ctx):
     assert (ex <= 16 * 2.0 ** -23 * mag).all()
 
 
+@pytest.mark.parametrize("S,D,spread,alpha,tol", [(16, 39, 3.0, 0.2, 1e-5), (5, 20, 3.0, 0.2, 1e-5),
+                                                  (16, 13, 6.0, 0.05, 5e-5), (8, 39, 4.0, 0.05, 5e-5)])
+def test_fused_estep_on_peaked_models(sra, ctx, S, D, spread, alpha, tol):
+    """The fused float32 E-step takes b~_t / c_t of its backward pass from the stored forward
+    vectors (alpha_t over the prediction A^T alpha_{t-1}).  Models with far-apart means, narrow
+    variances and sparse transition rows make those predictions and forward entries very small
+    or zero: utterances sampled from such models, statistics finite and equal to the float64
+    kernels' at 1e-5 of each array's largest entry (5e-5 for the widest spreads, where the
+    float32 emission itself -- mu^2 / sigma^2 of several thousand -- is no better; the
+    log-probability within 10 times that per frame for the same reason), and the float64 kernels equal
+    to the oracle on one model's utterances."""
+    rng = np.random.default_rng(S * 7 + D)
+    M, U = 3, 96
+    prms = []
+    for _ in range(M):
+        prms.append(ho.Params(rng.dirichlet(np.ones(S)), rng.dirichlet(np.ones(S) * alpha, size=S),
+                              rng.standard_normal((S, D)) * spread, rng.uniform(0.02, 0.1, (S, D))))
+    lengths = rng.integers(1, 120, size=U)
+    um = (np.arange(U) % M).astype(np.int32)
+    chunks = []
+    for u in range(U):
+        pr = prms[um[u]]
+        st = rng.choice(S, p=pr.pi)
+        rows = []
+        for _ in range(lengths[u]):
+            rows.append(pr.means[st] + rng.standard_normal(D) * np.sqrt(pr.covars[st]))
+            st = rng.choice(S, p=pr.A[st])
+        chunks.append(np.array(rows))
+    X = np.vstack(chunks)
+    bank = _bank(sra, ctx, prms)
+    umd = ctx.tensor(um)
+    ctx.set_estep_path("fused")
+    try:
+        s32 = bank.estep(sra.Ragged(ctx, X, lengths, dtype="float32"), umd).cpu().numpy()
+    finally:
+        ctx.set_estep_path("auto")
+    s64 = bank.estep(sra.Ragged(ctx, X, lengths, dtype="float64"), umd).cpu().numpy()
+    assert np.isfinite(s32).all() and np.isfinite(s64).all()
+    g32, g64 = bank.unpack_stats(ctx.tensor(s32)), bank.unpack_stats(ctx.tensor(s64))
+    for m in range(M):
+        assert g32[m]["nobs"] == g64[m]["nobs"]
+        assert abs(g32[m]["logprob"] - g64[m]["logprob"]) <= 10 * tol * lengths[um == m].sum()
+        for k in ("start", "trans", "post", "obs", "obs**2"):
+            np.testing.assert_allclose(g32[m][k], g64[m][k], rtol=0, atol=tol * np.abs(g64[m][k]).max())
+    # the float64 kernels against the oracle on model 0's utterances
+    sel = [u for u in range(U) if um[u] == 0]
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    st, lps = ho.estep(prms[0], np.vstack([X[off[u]:off[u + 1]] for u in sel]), [int(lengths[u]) for u in sel],
+                       loops=False)
+    assert abs(g64[0]["logprob"] - float(np.sum(lps))) <= 1e-9 * abs(float(np.sum(lps)))
+    for k in ("start", "trans", "post", "obs", "obs**2"):
+        np.testing.assert_allclose(g64[0][k], st[k], rtol=0, atol=1e-9 * max(1.0, np.abs(st[k]).max()))
+
+
 @pytest.mark.parametrize("M,S,D", [(1, 1, 1), (6, 3, 26), (5, 2, 9), (40, 4, 13), (7, 5, 48), (3, 6, 17),
                                    (9, 7, 33), (6, 8, 39)])
 def test_small_job_estep_paths_agree_with_oracle(sra, ctx, M, S, D):
