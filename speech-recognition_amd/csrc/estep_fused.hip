@@ -209,7 +209,6 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
     const int wsw = 4 * g ^ 4 * (ul >> 2);
     const int hsw = 2 * g ^ 4 * (ul >> 2);
 
-    int cur_model = -1;
     float w[KW];
     f32x4 c0, pi4;
     float atop[4], aop[4];
@@ -240,11 +239,14 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
         const int T_l = valid ? (int)(off[u + 1] - f_start) : 0;
         bool pending = valid && T_l > 0;
         const int64_t row_base = batch_base[k];
+        // (a batch of several models is walked once per model; the walks take the batch's
+        // lattice rows one after the other)
+        unsigned pass_base = 0;
         while (true) {
             const unsigned long long mask = __ballot(pending);
             if (mask == 0) break;
             const int first = __ffsll((long long)mask) - 1;
-            const int m_cur = __shfl(m_l, first, 64);
+            const int m_cur = __builtin_amdgcn_readfirstlane(__shfl(m_l, first, 64));
             // One descriptor addresses 4 GiB: of this model's utterances take those
             // within reach of the lowest one now, the rest in a later pass.
             const bool cand = pending && m_l == m_cur;
@@ -261,8 +263,9 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
             // (a single utterance beyond 4 GiB is not supported: its statistics are NaN)
             const bool active = span_ok ? fits : (cand && f_start == fmin);
             pending = pending && !active;
-            if (m_cur != cur_model) {
-                cur_model = m_cur;
+            // (read for every walk: kept across walks, the emission weights would hold their
+            // registers through the backward pass, which has none to spare)
+            {
                 const float* Wm = tb.W + (size_t)m_cur * 16 * KW * 4;
 #pragma unroll
                 for (int q = 0; q < KW; ++q) w[q] = Wm[((size_t)ul * KW + q) * 4 + g];
@@ -281,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
             int Tmax = T;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o, 64));
+            Tmax = __builtin_amdgcn_readfirstlane(Tmax);     // (wave-uniform values in scalar registers)
 
             // ---- descriptors: X from the lowest first row of the batch to its end,
             // the lattice from this batch's first row.  Offsets from kDrop up are out
@@ -348,11 +352,19 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                 return p0 + p1;
             };
 
+            // (each pass in a scope of its own: what only one of them needs is dead in the other)
+            // lattice rows of this walk: one per frame of its utterances
+            unsigned pass_rows = (unsigned)T;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) pass_rows += __shfl_xor(pass_rows, o, 64);
+            pass_rows = __builtin_amdgcn_readfirstlane(pass_rows);
+            double lp = 0.0;
+            unsigned rows_done = pass_base;               // wave-uniform
+            pass_base += span_ok ? pass_rows : 0u;
+            frame_t xq[PF];
+            {
             // ------------------------------------------------------ forward
             f32x4 alpha = {0.f, 0.f, 0.f, 0.f};
-            double lp = 0.0;
-            unsigned rows_done = 0;                       // wave-uniform
-            frame_t xq[PF];
             // (scheduling fences: the queue must fill oldest slot first, or the
             // loop's first wait has to cover every load in flight)
 #pragma unroll
@@ -396,7 +408,9 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                     loadx(t0 + i + PF, xq[(1 + i) % PF]);
                 }
             }
+            }
 
+            {
             // ----------------------------------------------------- backward
             // Two steps per iteration.  Step t is produced (recursion, then its
             // gamma / alpha / b~beta / frame tiles written to buffer t & 1 ...) while
@@ -590,18 +604,22 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                 }
             }
 
+            // ---------------- what is left of the batch sums
+            if constexpr (!POST) {
+                double* dst = my_rep + (size_t)m_cur * rec_size;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float ss = sum_u(start[reg]);
+                    const int s = 4 * reg + g;
+                    if (ul == 0 && s < S) unsafeAtomicAdd(dst + L.start + s, (double)ss);
+                }
+            }
+            }
+
             if constexpr (POST) {
                 if (active && g == 0) post_lp[u] = span_ok ? lp * kLn2 : __builtin_nan("");
             } else {
-            // ---------------- what is left of the batch sums
-            double* dst = my_rep + (size_t)m_cur * rec_size;
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const float ss = sum_u(start[reg]);
-                const int s = 4 * reg + g;
-                if (ul == 0 && s < S) unsafeAtomicAdd(dst + L.start + s, (double)ss);
-            }
-            {
+                double* dst = my_rep + (size_t)m_cur * rec_size;
                 double lps = span_ok ? lp : __builtin_nan("");
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) lps += __shfl_xor(lps, o, 64);
@@ -610,7 +628,6 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                     unsafeAtomicAdd(dst + L.logprob, lps * kLn2);
                     unsafeAtomicAdd(dst + L.nobs, (double)__popcll(am & 0xFFFFull));
                 }
-            }
             }
             wave_sync();
         }
