@@ -1086,6 +1086,7 @@ __global__ __launch_bounds__(64) void posteriors_lane_kernel(
     int n_tiles = (T_len + C - 1) / C;
 #pragma unroll
     for (int o = 32; o; o >>= 1) n_tiles = max(n_tiles, __shfl_xor(n_tiles, o));
+    n_tiles = __builtin_amdgcn_readfirstlane(n_tiles);          // (loop bounds in scalar registers)
     tile_sync();
 
     float A[S][S], pi[S];

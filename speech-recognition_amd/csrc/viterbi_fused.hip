@@ -130,6 +130,7 @@ __global__ __launch_bounds__(1024) void viterbi_fused_kernel(
     int Tmax = T;
 #pragma unroll
     for (int o = 32; o >= 8; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o, 64));
+    Tmax = __builtin_amdgcn_readfirstlane(Tmax);     // (loop bounds in scalar registers)
     if (Tmax <= 0) {
         if (valid && j == 0) out_lp[u] = 0.0;
         continue;
