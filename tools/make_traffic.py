@@ -133,7 +133,7 @@ if "estep_fused_kernel" in sec:
     e = sec["estep_fused_kernel"]
     e.update(workload="131,072 utterances x 200 frames x 39 dims, 6 models x 16 states", frames=fr,
              bytes_per_frame_measured=(e["FETCH_SIZE_bytes_per_launch"] + e["WRITE_SIZE_bytes_per_launch"]) / fr,
-             bytes_per_frame_design=448)
+             bytes_per_frame_design=440)
 if "cepstra_fast_kernel" in sec:
     c = sec["cepstra_fast_kernel"]
     c.update(workload="8192 recordings x 48,000 samples, 16 kHz, 512-point FFT", sample_bytes=8192 * 48000 * 4,
