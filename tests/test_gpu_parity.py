@@ -867,6 +867,14 @@ def test_fused_estep_on_peaked_models(sra, ctx, S, D, spread, alpha, tol):
         assert abs(g32[m]["logprob"] - g64[m]["logprob"]) <= 10 * tol * lengths[um == m].sum()
         for k in ("start", "trans", "post", "obs", "obs**2"):
             np.testing.assert_allclose(g32[m][k], g64[m][k], rtol=0, atol=tol * np.abs(g64[m][k]).max())
+    # posteriors of the same batch (models of more than 8 states: the same kernel, writing gamma)
+    lp32, p32 = bank.posteriors(sra.Ragged(ctx, X, lengths, dtype="float32"), umd)
+    lp64, p64 = bank.posteriors(sra.Ragged(ctx, X, lengths, dtype="float64"), umd)
+    p32, p64 = p32.cpu().numpy().astype(np.float64), p64.cpu().numpy()
+    assert np.isfinite(p32).all()
+    print("posteriors: largest |float32 - float64|", float(np.abs(p32 - p64).max()))
+    np.testing.assert_allclose(p32, p64, rtol=0, atol=20 * tol)
+    np.testing.assert_allclose(p32.sum(axis=1), 1.0, rtol=0, atol=1e-5)
     # the float64 kernels against the oracle on model 0's utterances
     sel = [u for u in range(U) if um[u] == 0]
     off = np.concatenate([[0], np.cumsum(lengths)])
