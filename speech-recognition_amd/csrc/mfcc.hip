@@ -388,15 +388,20 @@ __global__ void finish_kernel(const T* __restrict__ cep, const int64_t* __restri
 // repeated for the column means, the column variances and the write; only the
 // tile is re-read from global memory, and only when the utterance has several.
 // Summation orders are those of finish_kernel.
-template <typename T, int N>
-__global__ __launch_bounds__(256) void finish_stream_kernel(
+// KC: the number of cepstra when it is known at compile time (13, the reference's), else 0:
+// row strides and the thread-to-coefficient map are then immediates instead of scalar
+// registers and divisions.
+// (four workgroups per CU: an utterance's pass is a chain of memory round trips -- offsets,
+// tile, two reductions, stores -- and the workgroups in flight are what hides them)
+template <typename T, int N, int KC>
+__global__ __launch_bounds__(256, 4) void finish_stream_kernel(
     const T* __restrict__ cep, const int64_t* __restrict__ so, const int64_t* __restrict__ fo,
     int64_t U, MfccDev c, int order, int zscore, int tile_rows, T* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fin_raw[];
     T* tile = (T*)fin_raw;                      // [tile_rows + 4N][K]
     __shared__ double red[3 * 256];
     __shared__ T col_mean[128], col_scale[128];
-    const int K = c.n_ceps, NF = K * (1 + order);
+    const int K = KC ? KC : c.n_ceps, NF = K * (1 + order);
     const int nseg = blockDim.x / K, k = threadIdx.x % K, seg = threadIdx.x / K;
     int den = 0;
     for (int i = 1; i <= N; ++i) den += 2 * i * i;
@@ -433,11 +438,21 @@ __global__ __launch_bounds__(256) void finish_stream_kernel(
             }
             __syncthreads();
         };
-        // rows [lo, hi) of the utterance's cepstra -> tile
-        auto load_tile = [&](int64_t lo, int64_t hi) {
+        // rows [lo, hi) of the utterance's cepstra -> tile, from tile row `pad` on; with pad > 0
+        // the pad rows before them are copies of row lo and the pad rows behind them copies of
+        // row hi - 1 (the edge rule of the deltas, laid out so that no index needs a clamp)
+        auto load_tile = [&](int64_t lo, int64_t hi, int pad = 0) {
             __syncthreads();                    // walkers of the previous tile
             const int cnt = (int)(hi - lo) * K;
             const T* src = cu + lo * K;
+            T* tile = (T*)fin_raw + pad * K;
+            // (the edge rows are requested first and stored last: one round trip with the rest)
+            const bool edge = pad > 0 && (int)threadIdx.x < K;
+            T e_first = (T)0, e_last = (T)0;
+            if (edge) {
+                e_first = src[threadIdx.x];
+                e_last = src[cnt - K + threadIdx.x];
+            }
             // (8 loads in flight per thread: one at a time, the copy would take a
             // memory round trip per 256 elements)
             for (int i0 = threadIdx.x; i0 < cnt; i0 += 8 * blockDim.x) {
@@ -453,6 +468,11 @@ __global__ __launch_bounds__(256) void finish_stream_kernel(
                     if (i < cnt) tile[i] = v[q];
                 }
             }
+            if (edge)
+                for (int p_ = 1; p_ <= pad; ++p_) {
+                    tile[-p_ * K + (int)threadIdx.x] = e_first;
+                    tile[cnt + (p_ - 1) * K + (int)threadIdx.x] = e_last;
+                }
             __syncthreads();
         };
         // One walk of rows [a, b) (utterance rows; the tile starts at row lo): emit(q, t, v)
@@ -510,14 +530,60 @@ __global__ __launch_bounds__(256) void finish_stream_kernel(
                 for (int t = ra; t < rb; ++t) row(0, t);
             }
         };
+        // The walk over a tile whose pad rows hold the edge copies (whole utterance in the tile,
+        // tile row = utterance row + N): rows [ra, ra + UN) of the tile below rb, no clamps and
+        // no index products -- a pointer that moves down a row per step.  Same sums, in the
+        // same order, as walk.
+        auto walk_padded = [&](auto unroll, int ra, int rb, auto&& emit) {
+            constexpr int UN = decltype(unroll)::value;
+            auto d1 = [&](const T* p_) {
+                T v = 0;
+#pragma unroll
+                for (int j = -N; j <= N; ++j) {
+                    if (j == 0) continue;
+                    v += (T)j * p_[j * K];
+                }
+                return v * inv_den;
+            };
+            T w[2 * N + 1];
+#pragma unroll
+            for (int i = 0; i <= 2 * N; ++i) w[i] = (T)0;
+            const T* pc = tile + k + ra * K;
+            if (order >= 2) {
+#pragma unroll
+                for (int i = 0; i < 2 * N; ++i) w[i + 1] = d1(pc + (i - N) * K);
+            } else if (order == 1) {
+                w[N + 1] = d1(pc);
+            }
+#pragma unroll
+            for (int q = 0; q < UN; ++q)
+                if (ra + q < rb) {
+                    T v[3];
+                    v[0] = *pc;
+#pragma unroll
+                    for (int i = 0; i < 2 * N; ++i) w[i] = w[i + 1];
+                    if (order >= 2) {
+                        w[2 * N] = d1(pc + N * K);
+                        T a2 = 0;
+#pragma unroll
+                        for (int i = -N; i <= N; ++i) a2 += (T)i * w[N + i];
+                        v[2] = a2 * inv_den;
+                    } else {
+                        v[2] = (T)0;
+                        if (order == 1) w[N + 1] = d1(pc + K);
+                    }
+                    v[1] = w[N];
+                    emit(q, v);
+                    pc += K;
+                }
+        };
         const int first = zscore ? 0 : 2;
         // ---- short utterances, float32: one walk, the rows stay in registers
         constexpr int RMAX = 16;
         if constexpr (sizeof(T) == 4) {
             const int64_t per = (To + nseg - 1) / nseg;
             if (n_tiles == 1 && per <= RMAX) {
-                const int64_t lo = 0, hi = Tu;
-                load_tile(lo, hi);
+                load_tile(0, Tu, N);
                 const int64_t a = trim + seg * per;
                 const int64_t b = a + per < Tu - trim ? a + per : Tu - trim;
                 const bool mine = seg < nseg && a < b;
@@ -525,11 +591,12 @@ __global__ __launch_bounds__(256) void finish_stream_kernel(
 #pragma unroll
                 for (int q = 0; q < RMAX; ++q) r[q][0] = r[q][1] = r[q][2] = (T)0;
                 if (mine)
-                    walk(std::integral_constant<int, RMAX>{}, lo, a, b, [&](int q, int, const T (&v)[3]) {
-                        r[q][0] = v[0];
-                        r[q][1] = v[1];
-                        r[q][2] = v[2];
-                    });
+                    walk_padded(std::integral_constant<int, RMAX>{}, (int)a + N, (int)b + N,
+                                [&](int q, const T (&v)[3]) {
+                                    r[q][0] = v[0];
+                                    r[q][1] = v[1];
+                                    r[q][2] = v[2];
+                                });
                 const int nrow = mine ? (int)(b - a) : 0;
                 T mean[3] = {(T)0, (T)0, (T)0}, inv[3] = {(T)1, (T)1, (T)1};
                 if (zscore) {
@@ -674,8 +741,11 @@ bool launch_finish_stream(srx_context* h, const void* cep, const int64_t* so, co
     if (rows < 16) return false;
     int64_t grid = U < (int64_t)h->n_cu * 64 ? U : (int64_t)h->n_cu * 64;
 #define SRX_CASE(n)                                                                              \
-    if (N == n)                                                                                  \
-        hipLaunchKernelGGL((finish_stream_kernel<T, n>), dim3((unsigned)grid), dim3(256), lds, st, \
+    if (N == n && c.n_ceps == 13)                                                                \
+        hipLaunchKernelGGL((finish_stream_kernel<T, n, 13>), dim3((unsigned)grid), dim3(256), lds, st, \
+                           (const T*)cep, so, fo, U, d, c.delta_order, c.zscore, rows, (T*)out); \
+    else if (N == n)                                                                             \
+        hipLaunchKernelGGL((finish_stream_kernel<T, n, 0>), dim3((unsigned)grid), dim3(256), lds, st, \
                            (const T*)cep, so, fo, U, d, c.delta_order, c.zscore, rows, (T*)out);
     SRX_CASE(1) SRX_CASE(2) SRX_CASE(3)
 #undef SRX_CASE
