@@ -391,10 +391,16 @@ __global__ void finish_kernel(const T* __restrict__ cep, const int64_t* __restri
 // KC: the number of cepstra when it is known at compile time (13, the reference's), else 0:
 // row strides and the thread-to-coefficient map are then immediates instead of scalar
 // registers and divisions.
-// (four workgroups per CU: an utterance's pass is a chain of memory round trips -- offsets,
-// tile, two reductions, stores -- and the workgroups in flight are what hides them)
+// Workgroups of finish_stream_kernel a CU holds (158 registers with the next utterance's
+// cepstra in them; at four, 128 registers, the kernel spills)
+#define FIN_WG 3
+// Workgroup barrier that orders LDS accesses only: unlike __syncthreads it does not wait for
+// the global loads in flight (the next utterance's cepstra).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 template <typename T, int N, int KC>
-__global__ __launch_bounds__(256, 4) void finish_stream_kernel(
+__global__ __launch_bounds__(256, FIN_WG) void finish_stream_kernel(
     const T* __restrict__ cep, const int64_t* __restrict__ so, const int64_t* __restrict__ fo,
     int64_t U, MfccDev c, int order, int zscore, int tile_rows, T* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fin_raw[];
@@ -406,20 +412,64 @@ __global__ __launch_bounds__(256, 4) void finish_stream_kernel(
     int den = 0;
     for (int i = 1; i <= N; ++i) den += 2 * i * i;
     const T inv_den = (T)1 / (T)den;
+    const int trim = order > 0 ? N : 0;
+    constexpr int RMAX = 16;                    // rows a thread keeps in registers (short utterances)
+    // The cepstra of the workgroup's NEXT utterance, requested while the current one is worked
+    // on (float32 utterances short enough for the one-walk path; 16 KB of tile = 16 values per
+    // thread).  Every load is issued whatever the utterance is (an index outside it reads the
+    // array's first element): a load under a branch would be waited for where the branch ends.
+    // An utterance's shape (frames, first cepstra row, first output row) comes from the offset
+    // arrays two utterances ahead, so that neither the request above nor the walk waits for it.
+    constexpr int PRE = sizeof(T) == 4 ? 16 : 1;
+    T pre[PRE], pre_first = (T)0, pre_last = (T)0;
+    struct Shape {
+        int64_t Tu, To, row0, out0;
+        bool quick;                             // float32, one tile, at most RMAX rows per thread
+    };
+    auto shape = [&](int64_t u) {
+        const int64_t uu = u < U ? u : U - 1;
+        Shape sh;
+        sh.Tu = u < U ? raw_frames(c, so[uu + 1] - so[uu]) : 0;
+        sh.To = sh.Tu - 2 * trim > 0 ? sh.Tu - 2 * trim : 0;
+        sh.row0 = vpos(c, so, uu) / c.hop;
+        sh.out0 = fo[uu];
+        sh.quick = sizeof(T) == 4 && sh.To > 0 && sh.To <= tile_rows && (sh.To + nseg - 1) / nseg <= RMAX;
+        return sh;
+    };
+    auto prefetch = [&](const Shape& sh) {
+        if constexpr (sizeof(T) == 4) {
+            const bool ok = sh.quick;
+            const T* src = cep + (ok ? sh.row0 * K : 0);
+            const int cnt = ok ? (int)sh.Tu * K : 0;
+#pragma unroll
+            for (int q = 0; q < PRE; ++q) {
+                const int i = threadIdx.x + q * 256;
+                pre[q] = src[i < cnt ? i : 0];
+            }
+            const int e = (int)threadIdx.x < K ? (int)threadIdx.x : 0;
+            pre_first = src[cnt ? e : 0];
+            pre_last = src[cnt ? cnt - K + e : 0];
+        }
+    };
+    Shape sh_cur = shape(blockIdx.x), sh_nxt = shape((int64_t)blockIdx.x + gridDim.x);
+    prefetch(sh_cur);
     for (int64_t u = blockIdx.x; u < U; u += gridDim.x) {
-        const int64_t s0 = so[u], n = so[u + 1] - s0;
-        const int64_t Tu = raw_frames(c, n);
-        const int trim = order > 0 ? N : 0;
-        const int64_t To = Tu - 2 * trim > 0 ? Tu - 2 * trim : 0;
-        if (To == 0) continue;
-        const T* cu = cep + (vpos(c, so, u) / c.hop) * K;
-        T* ou = out + fo[u] * NF;
+        const Shape sh = sh_cur, sh_ahead = sh_nxt;
+        sh_cur = sh_nxt;
+        sh_nxt = shape(u + 2 * (int64_t)gridDim.x);
+        const int64_t Tu = sh.Tu, To = sh.To;
+        if (To == 0) {
+            prefetch(sh_ahead);
+            continue;
+        }
+        const T* cu = cep + sh.row0 * K;
+        T* ou = out + sh.out0 * NF;
         const int64_t n_tiles = (To + tile_rows - 1) / tile_rows;
         // column sums of a phase -> col_mean (phase 0) or col_scale (phase 1)
         auto reduce = [&](int phase, const double (&acc)[3]) {
 #pragma unroll
             for (int o = 0; o < 3; ++o) red[o * 256 + threadIdx.x] = seg < nseg ? acc[o] : 0.0;
-            __syncthreads();
+            lds_barrier();
             if (threadIdx.x < NF) {
                 const int o = threadIdx.x / K, kk = threadIdx.x % K;
                 double s = 0.0;
@@ -436,7 +486,7 @@ __global__ __launch_bounds__(256, 4) void finish_stream_kernel(
                     col_scale[threadIdx.x] = sc;
                 }
             }
-            __syncthreads();
+            lds_barrier();
         };
         // rows [lo, hi) of the utterance's cepstra -> tile, from tile row `pad` on; with pad > 0
         // the pad rows before them are copies of row lo and the pad rows behind them copies of
@@ -579,11 +629,28 @@ __global__ __launch_bounds__(256, 4) void finish_stream_kernel(
         };
         const int first = zscore ? 0 : 2;
         // ---- short utterances, float32: one walk, the rows stay in registers
-        constexpr int RMAX = 16;
         if constexpr (sizeof(T) == 4) {
             const int64_t per = (To + nseg - 1) / nseg;
             if (n_tiles == 1 && per <= RMAX) {
-                load_tile(0, Tu, N);
+                {
+                    // the tile from the registers filled one utterance ago (rows from tile row N
+                    // on, N edge copies either side), then the request for the next utterance
+                    lds_barrier();              // walkers of the previous tile
+                    const int cnt = (int)Tu * K;
+                    T* body = tile + N * K;
+#pragma unroll
+                    for (int q = 0; q < PRE; ++q) {
+                        const int i = threadIdx.x + q * 256;
+                        if (i < cnt) body[i] = pre[q];
+                    }
+                    if ((int)threadIdx.x < K)
+                        for (int p_ = 1; p_ <= N; ++p_) {
+                            body[-p_ * K + (int)threadIdx.x] = pre_first;
+                            body[cnt + (p_ - 1) * K + (int)threadIdx.x] = pre_last;
+                        }
+                    lds_barrier();
+                }
+                prefetch(sh_ahead);
                 const int64_t a = trim + seg * per;
                 const int64_t b = a + per < Tu - trim ? a + per : Tu - trim;
                 const bool mine = seg < nseg && a < b;
@@ -607,7 +674,7 @@ __global__ __launch_bounds__(256, 4) void finish_stream_kernel(
 #pragma unroll
                             for (int o = 0; o < 3; ++o) acc[o] += (double)r[q][o];
                         }
-                    __syncthreads();            // (red / col_* of the previous utterance)
+                    lds_barrier();              // (red / col_* of the previous utterance)
                     reduce(0, acc);
 #pragma unroll
                     for (int o = 0; o < 3; ++o) {
@@ -639,6 +706,7 @@ __global__ __launch_bounds__(256, 4) void finish_stream_kernel(
             }
         }
         // ---- any length: a walk per phase
+        prefetch(sh_ahead);
         if (threadIdx.x < NF) {
             col_mean[threadIdx.x] = (T)0;
             col_scale[threadIdx.x] = (T)1;
@@ -739,7 +807,10 @@ bool launch_finish_stream(srx_context* h, const void* cep, const int64_t* so, co
     const size_t lds = 16 * 1024;
     const int rows = (int)(lds / (sizeof(T) * (size_t)c.n_ceps)) - 4 * N;
     if (rows < 16) return false;
-    int64_t grid = U < (int64_t)h->n_cu * 64 ? U : (int64_t)h->n_cu * 64;
+    // (float32: the workgroups a CU holds, each walking its utterances with the next one's
+    // cepstra already requested)
+    const int64_t cap = (int64_t)h->n_cu * (sizeof(T) == 4 ? FIN_WG : 64);
+    int64_t grid = U < cap ? U : cap;
 #define SRX_CASE(n)                                                                              \
     if (N == n && c.n_ceps == 13)                                                                \
         hipLaunchKernelGGL((finish_stream_kernel<T, n, 13>), dim3((unsigned)grid), dim3(256), lds, st, \
