@@ -260,6 +260,31 @@ def test_front_end_beyond_2g_samples(sra, ctx):
     del feats, audio
 
 
+def test_front_end_ragged_batch_of_thousands(sra, ctx):
+    """3,000 recordings of 0 to 6 s in one float32 call: every workgroup of the delta / z-score
+    kernel walks several utterances, with the next one's cepstra requested ahead, through every
+    mixture of empty, short (one tile, rows kept in registers) and long (several tiles)
+    recordings.  Each checked recording gives exactly the features it gives on its own."""
+    import torch
+    rng = np.random.default_rng(77)
+    R = 3000
+    n = rng.integers(0, 6 * 16000, size=R)
+    n[rng.integers(0, R, size=40)] = rng.integers(0, 500, size=40)      # shorter than a frame or two
+    so = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    audio = torch.empty((int(so[-1]),), device="cuda", dtype=torch.float32).normal_(generator=g) * 0.1
+    for order, zscore in ((2, True), (1, True), (0, False)):
+        plan = sra.MfccPlan(ctx, 16000, nfft=512, n_mel=40, delta_order=order, zscore=zscore)
+        feats, fo = plan.run(audio, so)
+        assert bool(torch.isfinite(feats).all())
+        picks = list(rng.integers(0, R, size=60)) + [0, 1, R - 2, R - 1]
+        for r in picks:
+            one, fo1 = plan.run(audio[so[r]:so[r + 1]], [0, int(n[r])])
+            assert fo[r + 1] - fo[r] == fo1[1]
+            assert torch.equal(one, feats[fo[r]:fo[r + 1]]), (order, zscore, r, int(n[r]))
+
+
 def test_addressing_beyond_4gib(sra, ctx):
     """262,144 utterances x 200 x 39 floats = 7.6 GiB of features: results for
     utterances past the 4 GiB mark equal those of the same data processed on its own
