@@ -301,7 +301,9 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
             const __amdgpu_buffer_rsrc_t rsrc =
                 make_rsrc(X + fmin * D, span_ok ? (n_frames - fmin) * (int64_t)D * 4 : 0);
             const __amdgpu_buffer_rsrc_t rsrc_lat = make_rsrc(lat + row_base * 16, (n_frames - row_base) * 64);
-            const __amdgpu_buffer_rsrc_t rsrc_sc = make_rsrc(scale + row_base, (n_frames - row_base) * 4);
+            // (scale factors: only the kernel that recomputes the emission keeps them)
+            const __amdgpu_buffer_rsrc_t rsrc_sc =
+                make_rsrc(kRatio ? nullptr : scale + row_base, kRatio ? 0 : (n_frames - row_base) * 4);
             const int64_t f0 = active ? f_start : fmin;
             // (posteriors: rows of S floats, within the same reach as the rows of X)
             const __amdgpu_buffer_rsrc_t rsrc_post =
@@ -947,7 +949,8 @@ int srx_fused_estep(srx_context* h, const void* X, const int64_t* off, int64_t U
     float *lat, *scale;
     double* replicas;
     if ((rc = srx_ws_ensure(h, WS_LATTICE, sizeof(float) * (size_t)n_frames * 16, (void**)&lat))) return rc;
-    if ((rc = srx_ws_ensure(h, WS_SCALE, sizeof(float) * (size_t)n_frames, (void**)&scale))) return rc;
+    scale = nullptr;
+    if (!kRatio && (rc = srx_ws_ensure(h, WS_SCALE, sizeof(float) * (size_t)n_frames, (void**)&scale))) return rc;
     // (the replica records and, behind them, the counter that hands out the batches)
     const size_t rep_bytes = sizeof(double) * (size_t)kReplicas * M * rec_size;
     if ((rc = srx_ws_ensure(h, WS_PARTIAL, rep_bytes + 256, (void**)&replicas))) return rc;
@@ -1011,7 +1014,8 @@ int srx_fused_posteriors(srx_context* h, const void* X, const int64_t* off, int6
     tb.W = base; tb.cst = cst; tb.A = A; tb.pi = pi;
     float *lat, *scale;
     if ((rc = srx_ws_ensure(h, WS_LATTICE, sizeof(float) * (size_t)n_frames * 16, (void**)&lat))) return rc;
-    if ((rc = srx_ws_ensure(h, WS_SCALE, sizeof(float) * (size_t)n_frames, (void**)&scale))) return rc;
+    scale = nullptr;
+    if (!kRatio && (rc = srx_ws_ensure(h, WS_SCALE, sizeof(float) * (size_t)n_frames, (void**)&scale))) return rc;
     SRX_HIP(hipMemsetAsync(out_lp, 0, sizeof(double) * (size_t)U, st));
     // (the counter that hands out the batches)
     unsigned long long* queue;
