@@ -10,7 +10,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 struct row_t { u32x4 a, b; u32x2 c; };
 
 // MODE bit 0: read X, bit 1: write lattice, bit 2: read lattice, bit 3: descending time
-template <int MODE, int NV = 0, int NM = 0, int EARLY = 0, int SAUX = 0, int LAUX = 0>
+// BURST > 0: no scale factors, and the lattice blocks of BURST steps (a multiple of 3) are
+// written back to back after the last of them (what staging them in LDS would give)
+template <int MODE, int NV = 0, int NM = 0, int EARLY = 0, int SAUX = 0, int LAUX = 0, int BURST = 0>
 __global__ __launch_bounds__(256, 2) void k(const float* X, int64_t n_batches, int T, int D, float* lat,
                                             float* scale, float* out) {
     const int lane = threadIdx.x & 63, g = lane >> 4, ul = lane & 15;
@@ -67,10 +69,20 @@ __global__ __launch_bounds__(256, 2) void k(const float* X, int64_t n_batches, i
                         c[j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(v), 1.0f, c[j & 1], 0, 0, 0);
                     v ^= __float_as_uint(c[0][0] + c[1][1]);
                 }
-                if ((MODE & 2) && t0 + i < T) {
+                if ((MODE & 2) && t0 + i < T && BURST == 0) {
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{v, acc, v, acc}, rl,
                                                            (unsigned)(t0 + i) * 1024u + ul * 64u + 16u * g, 0, SAUX);
                     __builtin_amdgcn_raw_buffer_store_b32(v, rs, g == 0 ? (unsigned)(t0 + i) * 64u + ul * 4u : 0xFFFFFF00u, 0, SAUX);
+                }
+                if constexpr (BURST > 0) {
+                    if ((MODE & 2) && i == 2 && ((t0 + 3) % BURST == 0 || t0 + 3 >= T)) {
+                        const int first = (t0 + 3 - 1) / BURST * BURST;
+#pragma unroll
+                        for (int q = 0; q < BURST; ++q)
+                            __builtin_amdgcn_raw_buffer_store_b128(
+                                u32x4{v, acc, v, acc}, rl,
+                                first + q < T ? (unsigned)(first + q) * 1024u + ul * 64u + 16u * g : 0xFFFFFF00u, 0, SAUX);
+                    }
                 }
                 if (!EARLY) load(t0 + i + 3, s[i], al[i], sc[i]);
             }
@@ -79,14 +91,14 @@ __global__ __launch_bounds__(256, 2) void k(const float* X, int64_t n_batches, i
     out[blockIdx.x * 256 + threadIdx.x] = (float)acc;
 }
 
-template <int MODE, int NV = 0, int NM = 0, int EARLY = 0, int SAUX = 0, int LAUX = 0>
+template <int MODE, int NV = 0, int NM = 0, int EARLY = 0, int SAUX = 0, int LAUX = 0, int BURST = 0>
 void run(const char* what, double bytes_per_frame, const float* X, int64_t U, int T, int D, float* lat, float* scale,
          float* out) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int i = 0; i < 5; ++i) k<MODE, NV, NM, EARLY, SAUX, LAUX><<<512, 256>>>(X, U / 16, T, D, lat, scale, out);
+    for (int i = 0; i < 5; ++i) k<MODE, NV, NM, EARLY, SAUX, LAUX, BURST><<<512, 256>>>(X, U / 16, T, D, lat, scale, out);
     (void)hipEventRecord(e0);
-    for (int i = 0; i < 10; ++i) k<MODE, NV, NM, EARLY, SAUX, LAUX><<<512, 256>>>(X, U / 16, T, D, lat, scale, out);
+    for (int i = 0; i < 10; ++i) k<MODE, NV, NM, EARLY, SAUX, LAUX, BURST><<<512, 256>>>(X, U / 16, T, D, lat, scale, out);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -114,6 +126,11 @@ int main() {
     run<1, 100, 24>("read X + 100 FMAs + 24 matrix", 156, X, U, T, D, lat, scale, out);
     run<5 | 8, 150, 48>("backward + 150 FMAs + 48 matrix", 224, X, U, T, D, lat, scale, out);
     run<0, 150, 48>("no memory: 150 FMAs + 48 matrix", 224, X, U, T, D, lat, scale, out);
+    // the lattice blocks of several steps written back to back (no scale factors)
+    run<3, 0, 0, 0, 0, 0, 3>("forward, lattice of 3 steps at a time", 220, X, U, T, D, lat, scale, out);
+    run<3, 0, 0, 0, 0, 0, 6>("forward, lattice of 6 steps at a time", 220, X, U, T, D, lat, scale, out);
+    run<3, 0, 0, 0, 0, 0, 12>("forward, lattice of 12 steps at a time", 220, X, U, T, D, lat, scale, out);
+    run<3, 0, 0, 0, 0, 0, 24>("forward, lattice of 24 steps at a time", 220, X, U, T, D, lat, scale, out);
     // cache-policy bits of the lattice stores / loads (bit 0 sc0, bit 1 nt, bit 4 sc1)
     run<3, 0, 0, 0, 2, 0>("forward, lattice stores nt", 224, X, U, T, D, lat, scale, out);
     run<3, 0, 0, 0, 1, 0>("forward, lattice stores sc0", 224, X, U, T, D, lat, scale, out);
