@@ -449,12 +449,14 @@ def main():
         del feats_l
         # end-pointing pre-pass over the same recordings (10 ms block energies and
         # zero crossings, thresholds, run search)
-        ep = sra.endpoint.detect_batch(audio, so, 16000, ctx=ctx)
-        warm_gpu(lambda: sra.endpoint.detect_batch(audio, so, 16000, ctx=ctx))
+        # (the offsets of the batch layout go to the device once, like the front-end's)
+        lay = sra.endpoint.BatchLayout(so, 16000, ctx=ctx)
+        ep = sra.endpoint.detect_batch(audio, lay, 16000, ctx=ctx)
+        warm_gpu(lambda: sra.endpoint.detect_batch(audio, lay, 16000, ctx=ctx))
         barrier()
         t0 = time.perf_counter()
         for _ in range(reps):
-            ep = sra.endpoint.detect_batch(audio, so, 16000, ctx=ctx)
+            ep = sra.endpoint.detect_batch(audio, lay, 16000, ctx=ctx)
         barrier()
         dte = (time.perf_counter() - t0) / reps
         extra["endpoint"] = {"samples_per_s": n_utt_fe * n_samp * world / dte, "ms": dte * 1e3,

