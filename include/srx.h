@@ -126,8 +126,16 @@ int srx_destroy(srx_handle_t h);
  * and at most 48 features: SRX_VITERBI_AUTO (0, default) and SRX_VITERBI_FUSED (1) decode in
  * one kernel that keeps the log-densities on the chip (it measured faster than the other path
  * at every batch size from 128 utterances up), SRX_VITERBI_SPLIT (2) in two (log-densities to
- * memory, then the recursion; tests, timing).  Same states and log-probabilities, bit for bit. */
-enum srx_option { SRX_OPT_EXACT_F32 = 1, SRX_OPT_ESTEP_PATH = 2, SRX_OPT_VITERBI_PATH = 3 };
+ * memory, then the recursion; tests, timing).  Same states and log-probabilities, bit for bit.
+ * SRX_OPT_ESTEP_STATS says which statistics the caller of srx_estep_stats will use:
+ * SRX_STATS_ALL (0, default) or SRX_STATS_TRANSITIONS (1) -- nobs, logprob, start and trans
+ * only, what the reference's own fit() re-estimates from (do_em_mstep, my_hmmlearn/hmm.py:237-253;
+ * srx_mstep in SRX_MSTEP_TRANSITIONS_ONLY mode).  The post, obs and obs2 entries of the records
+ * are then either complete or all zero: the kernels of small jobs skip their pass over the
+ * features, the others compute everything as before. */
+enum srx_option { SRX_OPT_EXACT_F32 = 1, SRX_OPT_ESTEP_PATH = 2, SRX_OPT_VITERBI_PATH = 3,
+                  SRX_OPT_ESTEP_STATS = 4 };
+enum srx_estep_stats { SRX_STATS_ALL = 0, SRX_STATS_TRANSITIONS = 1 };
 enum srx_estep_path { SRX_ESTEP_AUTO = 0, SRX_ESTEP_FUSED = 1, SRX_ESTEP_LANE = 2 };
 enum srx_viterbi_path { SRX_VITERBI_AUTO = 0, SRX_VITERBI_FUSED = 1, SRX_VITERBI_SPLIT = 2 };
 int srx_set_option(srx_handle_t h, int option, int value);

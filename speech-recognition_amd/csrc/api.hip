@@ -149,6 +149,10 @@ int srx_set_option(srx_handle_t h, int option, int value) {
             SRX_REQUIRE(value >= SRX_VITERBI_AUTO && value <= SRX_VITERBI_SPLIT, "srx_set_option: unknown Viterbi path %d", value);
             h->viterbi_path = value;
             return SRX_OK;
+        case SRX_OPT_ESTEP_STATS:
+            SRX_REQUIRE(value == SRX_STATS_ALL || value == SRX_STATS_TRANSITIONS, "srx_set_option: unknown statistics selection %d", value);
+            h->estep_stats = value;
+            return SRX_OK;
         default: srx_set_error("srx_set_option: unknown option %d", option); return SRX_EINVAL;
     }
 }

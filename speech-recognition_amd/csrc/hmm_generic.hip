@@ -1870,14 +1870,18 @@ int estep_lane(srx_context* h, const void* X, const int64_t* off, int64_t U, int
 #define OBS(NC)                                                                                   \
     hipLaunchKernelGGL((obs_stats_f32_mfma_kernel<NC>), dim3(g_obs), dim3(64), 0, st, (const float*)X, \
                        (const float*)lat, off, U, utt_model, utt_order, M, S, D, part_obs)
-    if (D <= 16) OBS(1);
+    // (a caller that re-estimates start and transition probabilities only gets zeros for
+    // the sums over the features: no pass over X)
+    const bool with_obs = h->estep_stats != SRX_STATS_TRANSITIONS;
+    if (!with_obs) {
+    } else if (D <= 16) OBS(1);
     else if (D <= 32) OBS(2);
     else OBS(3);
 #undef OBS
     const int64_t n_out = (int64_t)M * (P + Q);                  // one wave per output sum
     const int g_red = (int)std::min<int64_t>((n_out * 64 + kBlock - 1) / kBlock, 4096);
     hipLaunchKernelGGL(reduce_stats_kernel, dim3(g_red), dim3(kBlock), 0, st, (const double*)part, g_fb,
-                       (const double*)part_obs, g_obs, M, S, D, out_stats);
+                       (const double*)part_obs, with_obs ? g_obs : 0, M, S, D, out_stats);
     SRX_HIP(hipGetLastError());
     return SRX_OK;
 }
@@ -1916,12 +1920,17 @@ int estep_lane_f64(srx_context* h, const void* X, const int64_t* off, int64_t U,
                            part, M);
     SRX_CASE(1) SRX_CASE(2) SRX_CASE(3) SRX_CASE(4) SRX_CASE(5) SRX_CASE(6) SRX_CASE(7) SRX_CASE(8)
 #undef SRX_CASE
-    rc = srx_mfma_obs_stats_f64(h, X, lat, off, U, utt_model, utt_order, md, part_obs, g_obs, st);
-    if (rc) return rc;
+    // (a caller that re-estimates start and transition probabilities only gets zeros for
+    // the sums over the features: no pass over X)
+    const bool with_obs = h->estep_stats != SRX_STATS_TRANSITIONS;
+    if (with_obs) {
+        rc = srx_mfma_obs_stats_f64(h, X, lat, off, U, utt_model, utt_order, md, part_obs, g_obs, st);
+        if (rc) return rc;
+    }
     const int64_t n_out = (int64_t)M * (P + Q);
     const int g_red = (int)std::min<int64_t>((n_out * 64 + kBlock - 1) / kBlock, 4096);
     hipLaunchKernelGGL(reduce_stats_kernel, dim3(g_red), dim3(kBlock), 0, st, (const double*)part, g_fb,
-                       (const double*)part_obs, g_obs, M, S, D, out_stats);
+                       (const double*)part_obs, with_obs ? g_obs : 0, M, S, D, out_stats);
     SRX_HIP(hipGetLastError());
     return SRX_OK;
 }

@@ -318,19 +318,25 @@ class MyGaussianHMM:
         snap = None
         stats = None
         stopped = False
-        for k in range(n_iter):
-            stats = bank.estep(data, out=stats)
-            logp[k:k + 1].copy_(stats[0, 1:2], non_blocking=True)
-            snap = bank.snapshot(snap)                          # parameters before M-step k
-            bank.mstep(stats, pri, self.mstep)
-            events[k % 2].record()
-            if k >= 1:
-                events[(k - 1) % 2].synchronize()
-                self.monitor_.report(float(logp[k - 1]))
-                if self.monitor_.converged:
-                    bank.restore(snap)                          # drop iteration k
-                    stopped = True
-                    break
+        # (the reference's own M-step uses the start and transition sums only: the E-step of a
+        # small job then skips its pass over the features)
+        bank.ctx.set_estep_stats("transitions" if self.mstep == "transitions_only" else "all")
+        try:
+            for k in range(n_iter):
+                stats = bank.estep(data, out=stats)
+                logp[k:k + 1].copy_(stats[0, 1:2], non_blocking=True)
+                snap = bank.snapshot(snap)                      # parameters before M-step k
+                bank.mstep(stats, pri, self.mstep)
+                events[k % 2].record()
+                if k >= 1:
+                    events[(k - 1) % 2].synchronize()
+                    self.monitor_.report(float(logp[k - 1]))
+                    if self.monitor_.converged:
+                        bank.restore(snap)                      # drop iteration k
+                        stopped = True
+                        break
+        finally:
+            bank.ctx.set_estep_stats("all")
         if not stopped and n_iter >= 1:
             events[(n_iter - 1) % 2].synchronize()
             self.monitor_.report(float(logp[n_iter - 1]))

@@ -76,6 +76,14 @@ class Context:
         code = {"auto": _lib.SRX_ESTEP_AUTO, "fused": _lib.SRX_ESTEP_FUSED, "lane": _lib.SRX_ESTEP_LANE}[path]
         check(lib.srx_set_option(self._h, _lib.SRX_OPT_ESTEP_PATH, code), "srx_set_option")
 
+    def set_estep_stats(self, which):
+        """What the caller of the E-step will use: "all" statistics or "transitions" (count,
+        log-probability, start and transition sums: what the reference's own fit()
+        re-estimates from, my_hmmlearn/hmm.py:237-253).  With "transitions" the sums over the
+        features come back complete or all zero; small jobs skip their pass over X."""
+        code = {"all": _lib.SRX_STATS_ALL, "transitions": _lib.SRX_STATS_TRANSITIONS}[which]
+        check(lib.srx_set_option(self._h, _lib.SRX_OPT_ESTEP_STATS, code), "srx_set_option")
+
     def set_viterbi_path(self, path):
         """Kernels of float32 Viterbi decoding for models of at most 8 states: "auto" / "fused"
         (one kernel, log-densities kept on the chip) or "split" (an emission kernel, then a
