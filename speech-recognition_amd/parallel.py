@@ -96,7 +96,13 @@ class BaumWelchTrainer:
     def step(self):
         """One EM iteration; returns the per-model log-probabilities (device
         tensor, computed with the parameters before the update)."""
-        self.bank.estep(self.data, self.utt_model, self.utt_order, out=self.stats)
+        # (a transitions-only M-step reads no sum over the features: small jobs skip that pass)
+        ctx = self.bank.ctx
+        ctx.set_estep_stats("transitions" if self.mode == "transitions_only" else "all")
+        try:
+            self.bank.estep(self.data, self.utt_model, self.utt_order, out=self.stats)
+        finally:
+            ctx.set_estep_stats("all")
         allreduce_stats(self.stats)
         logprob = self.stats[:, 1].clone()
         self.bank.mstep(self.stats, self.priors, self.mode)

@@ -188,6 +188,9 @@ class _OracleBank:
             import torch
             return torch.from_numpy(np.ascontiguousarray(a))
 
+        def set_estep_stats(self, which):       # (the oracle-backed E-step computes everything)
+            assert which in ("all", "transitions")
+
     def __init__(self, params, X, lengths):
         from oracle import hmm_oracle as ho
         self.ho, self.ctx = ho, self._Ctx()
