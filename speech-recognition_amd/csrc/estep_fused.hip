@@ -178,7 +178,11 @@ struct Frame {
 // POST = true is the posteriors variant of the same forward-backward pass: gamma of
 // every frame goes to post_out[frame][state] and the utterance's log-probability to
 // post_lp[utterance]; the accumulating products and the statistics are left out.
-template <int RQ, int H, int NTX, bool POST = false>
+// OBS = false leaves out the sums over the features (post, obs, obs2 stay zero): the E-step
+// of a caller that re-estimates start and transition probabilities only.  The backward pass
+// then reads the lattice alone -- as it does in the posteriors variant, which needs the
+// frames for nothing once b~ comes from the lattice.
+template <int RQ, int H, int NTX, bool POST = false, bool OBS = true>
 __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
     const float* __restrict__ X, const int64_t* __restrict__ off, int64_t U, int64_t n_frames,
     const int32_t* __restrict__ utt_model, const int64_t* __restrict__ utt_order, int M, int S,
@@ -441,11 +445,12 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
             // (issued in the order the loop issues them, so that its waits stay counted)
             loada(Tmax - 1, alq[0], ciq[0]);
             __builtin_amdgcn_sched_barrier(0);
-            loadx(Tmax - 1, xq[0]);
+            constexpr bool kFrames = !POST && OBS;      // the backward pass reads X
+            if constexpr (kFrames) loadx(Tmax - 1, xq[0]);
             __builtin_amdgcn_sched_barrier(0);
             loada(Tmax - 2, alq[1], ciq[1]);
             __builtin_amdgcn_sched_barrier(0);
-            loadx(Tmax - 2, xq[1]);
+            if constexpr (kFrames) loadx(Tmax - 2, xq[1]);
             __builtin_amdgcn_sched_barrier(0);
             loada(Tmax - 3, alq[2], ciq[2]);
             __builtin_amdgcn_sched_barrier(0);
@@ -470,24 +475,28 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                         const int row = (4 * q + g) * 16 + (ul ^ 4 * q);
                         aa[qq] = t_alp[row];
                         ba[qq] = t_bb[row];
-                        ga[qq] = t_gam[row];
+                        if constexpr (OBS) {
+                            ga[qq] = t_gam[row];
 #pragma unroll
-                        for (int nt = 0; nt < NTX; ++nt) {
-                            // column c of [x (DP wide) | x^2 (DP wide)]
-                            const int c = 16 * nt + ul;
-                            const int d = c < DP ? c : c - DP;
-                            xa[qq][nt] = t_x[(4 * q + g) * XS + (d ^ 4 * q)];
+                            for (int nt = 0; nt < NTX; ++nt) {
+                                // column c of [x (DP wide) | x^2 (DP wide)]
+                                const int c = 16 * nt + ul;
+                                const int d = c < DP ? c : c - DP;
+                                xa[qq][nt] = t_x[(4 * q + g) * XS + (d ^ 4 * q)];
+                            }
                         }
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (3 + NTX), 0);   // DS reads
+                    __builtin_amdgcn_sched_group_barrier(0x100, OBS ? 2 * (3 + NTX) : 4, 0);   // DS reads
 #pragma unroll
                     for (int qq = 0; qq < 2; ++qq) {
                         G = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[qq], ba[qq], G, 0, 0, 0);
+                        if constexpr (OBS) {
 #pragma unroll
-                        for (int nt = 0; nt < NTX; ++nt) {
-                            float xv = xa[qq][nt];
-                            if (16 * nt + ul >= DP) xv *= xv;
-                            O[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[qq], xv, O[nt], 0, 0, 0);
+                            for (int nt = 0; nt < NTX; ++nt) {
+                                float xv = xa[qq][nt];
+                                if (16 * nt + ul >= DP) xv *= xv;
+                                O[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[qq], xv, O[nt], 0, 0, 0);
+                            }
                         }
                     }
                 }
@@ -540,18 +549,20 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                             live && 4 * q + g < S ? post_row + (unsigned)t * (unsigned)(S * 4) + (unsigned)(4 * q + g) * 4u
                                                   : kDrop, 0, 0);
                 } else {
-                    *(f32x4*)(t_gam + ul * 16 + wsw) = gam;
                     *(f32x4*)(t_alp + ul * 16 + wsw) = al;
                     *(f32x4*)(t_bb + ul * 16 + wsw) = bb;
+                    if constexpr (OBS) {
+                        *(f32x4*)(t_gam + ul * 16 + wsw) = gam;
 #pragma unroll
-                    for (int q = 0; q < RQ; ++q) {
-                        // (a finished utterance keeps its last frame here: its gamma is 0)
-                        *(u32x4*)(t_x + ul * XS + 16 * q + wsw) = xc.v[q];
+                        for (int q = 0; q < RQ; ++q) {
+                            // (a finished utterance keeps its last frame here: its gamma is 0)
+                            *(u32x4*)(t_x + ul * XS + 16 * q + wsw) = xc.v[q];
+                        }
+                        if constexpr (H != 0) {
+                            *(u32x2*)(t_x + ul * XS + 16 * RQ + hsw) = xc.h;
+                        }
+                        post += gam;
                     }
-                    if constexpr (H != 0) {
-                        *(u32x2*)(t_x + ul * XS + 16 * RQ + hsw) = xc.h;
-                    }
-                    post += gam;
                     if (t == 0) start = gam;
                 }
                 bb = live ? b * beta : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -568,21 +579,25 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                     const int si = sigma(4 * g + reg), sj = sigma(ul);
                     if (si < S && sj < S) unsafeAtomicAdd(dst + L.trans + si * S + sj, (double)G[reg]);
                     G[reg] = 0.f;
+                    if constexpr (OBS) {
 #pragma unroll
-                    for (int nt = 0; nt < NTX; ++nt) {
-                        const int c = 16 * nt + ul;
-                        const int d = c < DP ? c : c - DP;
-                        if (si < S && d < D)
-                            unsafeAtomicAdd(dst + (c < DP ? L.obs : L.obs2) + si * D + d, (double)O[nt][reg]);
-                        O[nt][reg] = 0.f;
+                        for (int nt = 0; nt < NTX; ++nt) {
+                            const int c = 16 * nt + ul;
+                            const int d = c < DP ? c : c - DP;
+                            if (si < S && d < D)
+                                unsafeAtomicAdd(dst + (c < DP ? L.obs : L.obs2) + si * D + d, (double)O[nt][reg]);
+                            O[nt][reg] = 0.f;
+                        }
                     }
                 }
+                if constexpr (OBS) {
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const float ps = sum_u(post[reg]);
-                    const int s = 4 * reg + g;
-                    if (ul == 0 && s < S) unsafeAtomicAdd(dst + L.post + s, (double)ps);
-                    post[reg] = 0.f;
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const float ps = sum_u(post[reg]);
+                        const int s = 4 * reg + g;
+                        if (ul == 0 && s < S) unsafeAtomicAdd(dst + L.post + s, (double)ps);
+                        post[reg] = 0.f;
+                    }
                 }
             };
             // (the walk is cut into runs of kFlushSteps steps with one flush after each)
@@ -595,7 +610,7 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                         const int t = t0 - i;             // t < 0: a dead step, writes zero tiles
                         if constexpr (!POST) consume(tiles + TILE * ((i & 1) ^ 1));
                         produce(t, tiles + TILE * (i & 1), xq[i & 1], alq[i], ciq[i], alq[(i + 1) & 3]);
-                        loadx(t - 2, xq[i & 1]);
+                        if constexpr (kFrames) loadx(t - 2, xq[i & 1]);
                         loada(t - 3, alq[(i + 3) & 3], ciq[(i + 3) & 3]);
                         if constexpr (!POST) wave_sync();
                     }
@@ -728,20 +743,20 @@ __global__ void fused_finish_kernel(const double* __restrict__ replicas, srx_mod
     }
 }
 
-template <int RQ, int H, int NTX, bool POST = false>
+template <int RQ, int H, int NTX, bool POST = false, bool OBS = true>
 int launch(srx_context* h, const float* X, const int64_t* off, int64_t U, int64_t n_frames,
            const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* md,
            FusedTables tb, const int64_t* batch_base, float* lat, float* scale, double* replicas,
            int rec_size, hipStream_t st, float* post_out = nullptr, double* post_lp = nullptr,
            unsigned long long* queue = nullptr) {
     const size_t lds = POST ? 0 : sizeof(float) * 2 * (3 * 256 + 16 * frame_tile_stride(16 * RQ + 8 * H)) * kWavesPerBlock;
-    auto kern = estep_fused_kernel<RQ, H, NTX, POST>;
+    auto kern = estep_fused_kernel<RQ, H, NTX, POST, OBS>;
     SRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
     const int64_t n_groups = (U + 15) / 16;
     int64_t grid = (n_groups + kWavesPerBlock - 1) / kWavesPerBlock;
     // (the posteriors variant needs fewer registers: three workgroups per CU)
-    const int64_t cap = (int64_t)h->n_cu * (POST ? 3 : 2);
+    const int64_t cap = (int64_t)h->n_cu * (POST || !OBS ? 3 : 2);
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kWavesPerBlock), lds, st, X, off, U,
@@ -972,11 +987,18 @@ int srx_fused_estep(srx_context* h, const void* X, const int64_t* off, int64_t U
                        (const int64_t*)block_sum, batch_base);
     hipLaunchKernelGGL(fused_prep_kernel, dim3(24), dim3(256), 0, st, *md, RQ, H, base, cst, A, pi);
     const float* Xf = (const float*)X;
+    // (a caller that re-estimates start and transition probabilities only: no sums over the
+    // features, and a backward pass that reads the lattice alone)
+    const bool with_obs = h->estep_stats != SRX_STATS_TRANSITIONS;
 #define SRX_CASE(rq, hh, ntx)                                                                \
     if (RQ == rq && H == hh && NTX == ntx) {                                                  \
-        rc = launch<rq, hh, ntx>(h, Xf, off, E, n_frames, utt_model, utt_order, md, tb,       \
-                                 batch_base, lat, scale, replicas, rec_size, st, nullptr,     \
-                                 nullptr, queue);                                             \
+        rc = with_obs ? launch<rq, hh, ntx>(h, Xf, off, E, n_frames, utt_model, utt_order, md, \
+                                            tb, batch_base, lat, scale, replicas, rec_size,   \
+                                            st, nullptr, nullptr, queue)                      \
+                      : launch<rq, hh, ntx, false, false>(h, Xf, off, E, n_frames, utt_model, \
+                                                          utt_order, md, tb, batch_base, lat, \
+                                                          scale, replicas, rec_size, st,      \
+                                                          nullptr, nullptr, queue);           \
     } else
     SRX_CASE(0, 1, 1) SRX_CASE(1, 0, 2) SRX_CASE(1, 1, 3) SRX_CASE(2, 0, 4) SRX_CASE(2, 1, 5)
     SRX_CASE(3, 0, 6)

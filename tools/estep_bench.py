@@ -24,6 +24,8 @@ um = torch.as_tensor(um_host, dtype=torch.int32, device='cuda')
 order = None
 if os.environ.get("ES_ORDER") == "memory":
     order = torch.as_tensor(np.argsort(um_host, kind="stable").astype(np.int64), device='cuda')
+if os.environ.get("ES_STATS"):          # "transitions": the E-step of a transitions-only M-step
+    ctx.set_estep_stats(os.environ["ES_STATS"])
 out = None
 for _ in range(6):
     out = bank.estep(data, um, order, out=out)
