@@ -555,6 +555,24 @@ def main():
                 sra.parallel.allreduce_stats(buf)
             torch.cuda.synchronize()
             ar_ms = (time.perf_counter() - t0) / 50 * 1e3
+        # the same iteration as the reference's own fit() runs it: start and transition
+        # probabilities only (my_hmmlearn/hmm.py:213), reported beside the full one
+        bank3 = sra.HMMBank(ctx, sp2, A2, mu2, cv2)
+        tr3 = sra.parallel.BaumWelchTrainer(bank3, dt_, np.arange(Ut) % N_MODELS, mstep="transitions_only")
+        for _ in range(2):
+            tr3.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            tr3.step()
+        barrier()
+        dt3 = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt3], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt3 = float(t.item())
+        dt3 /= iters
+        del tr3, bank3
         out["baum_welch_iter_per_s"] = 1.0 / dtt
         out["allreduce_ms_per_iter"] = ar_ms
         out["rccl_ranks"] = ranks_seen
@@ -565,7 +583,9 @@ def main():
                                "config": "6 models x 16 states x 39 dims, full M-step, one all-reduce of "
                                          f"{tr.stats.numel()} float64 per iteration",
                                "allreduce_ms": ar_ms, "rccl_ranks": ranks_seen,
-                               "logprob_model0": float(lp[0].item())}
+                               "logprob_model0": float(lp[0].item()),
+                               "transitions_only_iter_per_s": 1.0 / dt3,
+                               "transitions_only_ms_per_iter": dt3 * 1e3}
         del Xt, dt_, tr
     if extra:
         out["extra"] = extra
