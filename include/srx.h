@@ -250,7 +250,10 @@ int srx_viterbi(srx_handle_t h, const void* X, int dtype, const int64_t* utt_off
  * hmm.py:308-328, utils.py:169-183, :6-30.  out_posteriors[f, s] (dtype) is the
  * row-normalised product of the scaled forward and backward lattices under the
  * utterance's model utt_model[u] (NULL = model 0); out_logprob[u] the forward
- * log-probability. */
+ * log-probability.  out_posteriors also serves as the kernels' scratch while the call's
+ * stream work runs (forward vectors are parked in its rows before the posteriors replace
+ * them): read it only after that work is done.  SRX_F32, at most 8 states: an array that is
+ * 16-byte aligned and smaller than 4 GiB takes the faster kernel; same results otherwise. */
 int srx_posteriors(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
                    int64_t n_utts, int64_t n_frames, const int32_t* utt_model,
                    const srx_models_t* models, void* out_posteriors, double* out_logprob,
