@@ -6,6 +6,8 @@ import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import speech_recognition_amd as sra
 from oracle import hmm_oracle as ho
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from conftest import assert_ties_only
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -55,7 +57,14 @@ for case in range(n_cases):
             assert abs(lp_p[u] - rl[0]) < 1e-4 * tight * abs(rl[0]), "posterior logprob"
             vlp, vpath = ho.viterbi(prms[um[u]], x, [n])
             assert abs(lp_v[u] - vlp[0]) < 1e-4 * tight * abs(vlp[0]), "viterbi logprob"
-            assert np.mean(path[off[u]:off[u + 1]] == vpath) > (0.9 if dtype == "float32" else 0.999), "viterbi path"
+            if dtype == "float64":
+                assert np.array_equal(path[off[u]:off[u + 1]], vpath), "viterbi path"
+            elif not np.array_equal(path[off[u]:off[u + 1]], vpath):
+                # float32: the paths may part at near-ties of the float64 lattice only, and the
+                # float32 path must reach the optimum under the float64 model
+                pr = prms[um[u]]
+                assert_ties_only(pr.pi, pr.A, ho.log_density_diag(x, pr.means, pr.covars), [n], path[off[u]:off[u + 1]], vpath,
+                                 vlp[0], eps=2e-5)
         for m in range(M):
             sel = [u for u in range(U) if um[u] == m and lengths[u] > 0]
             if not sel:
