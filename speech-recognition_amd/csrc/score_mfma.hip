@@ -439,13 +439,19 @@ __global__ __launch_bounds__(256) void emission_utt_split_kernel(
 // split-bf16 product).  Weight table per model: one 16-row tile,
 // W[row][q][x | x^2][g][i] = coefficient of feature 16 q + 4 g + i, natural-log units;
 // lane (g, ul) keeps row ul's coefficients for its own k slots in registers.
-__global__ void emission_f32_prep_kernel(srx_models_t md, int RQ, float* W, float* cst) {
+// With H the last 8 features form a half block of their own, [x | x^2][g][i < 2] = feature
+// 16 RQ + 2 g + i, behind the RQ full blocks (the scoring kernel's cut of the feature axis: a
+// 39-feature row is read in 160 bytes and takes 20 matrix instructions instead of 24).
+__global__ void emission_f32_prep_kernel(srx_models_t md, int RQ, int H, float* W, float* cst) {
     const int M = md.n_models, S = md.n_states, D = md.n_features;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
-    const int per_row = RQ * 32;
+    const int per_row = RQ * 32 + H * 16;
     for (int i = tid; i < M * 16 * per_row; i += nth) {
         const int row = i / per_row, w = i % per_row;
-        const int q = w >> 5, e = (w >> 4) & 1, d = 16 * q + (w & 15);
+        const int hw = w - RQ * 32;                  // >= 0: inside the half block
+        const int q = w >> 5;
+        const int e = hw >= 0 ? hw >> 3 : (w >> 4) & 1;
+        const int d = hw >= 0 ? 16 * RQ + (hw & 7) : 16 * q + (w & 15);
         const int m = row >> 4, s_ = row & 15;
         float v = 0.f;
         if (s_ < S && d < D) {
@@ -473,7 +479,7 @@ __global__ void emission_f32_prep_kernel(srx_models_t md, int RQ, float* W, floa
     }
 }
 
-template <int RQ>
+template <int RQ, int H>
 __global__ __launch_bounds__(256) void emission_utt_f32_kernel(
     const float* __restrict__ X, const int64_t* __restrict__ off, int64_t U, int64_t n_frames,
     const int32_t* __restrict__ utt_model, int S, int D, const float* __restrict__ W,
@@ -482,8 +488,11 @@ __global__ __launch_bounds__(256) void emission_utt_f32_kernel(
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const unsigned lane_off = (unsigned)ul * (unsigned)D * 4u + 16u * g;
+    const unsigned half_off = (unsigned)ul * (unsigned)D * 4u + 64u * RQ + 8u * g;
+    constexpr int PER_ROW = RQ * 32 + H * 16;
     int cur = -1;
-    f32x4 w1[RQ], w2[RQ];
+    f32x4 w1[RQ ? RQ : 1], w2[RQ ? RQ : 1];
+    float wh1[2] = {0.f, 0.f}, wh2[2] = {0.f, 0.f};
     f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < RQ; ++q) w1[q] = w2[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -496,15 +505,20 @@ __global__ __launch_bounds__(256) void emission_utt_f32_kernel(
             cur = m;
 #pragma unroll
             for (int q = 0; q < RQ; ++q) {
-                const float* p = W + (((size_t)(m * 16 + ul)) * RQ + q) * 32 + 4 * g;
+                const float* p = W + ((size_t)(m * 16 + ul)) * PER_ROW + q * 32 + 4 * g;
                 w1[q] = *(const f32x4*)p;
                 w2[q] = *(const f32x4*)(p + 16);
+            }
+            if constexpr (H != 0) {
+                const float* p = W + ((size_t)(m * 16 + ul)) * PER_ROW + RQ * 32 + 2 * g;
+                wh1[0] = p[0]; wh1[1] = p[1];
+                wh2[0] = p[8]; wh2[1] = p[9];
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) c0[r] = cst[m * 16 + 4 * g + r];
         }
         const int64_t n_groups = (T + 15) / 16;
-        auto load = [&](int64_t k, u32x4 (&dst)[RQ]) {
+        auto load = [&](int64_t k, u32x4 (&dst)[RQ ? RQ : 1], u32x2& dh) {
             // descriptor over [first frame of the group, end of the utterance)
             const int64_t fk = k < n_groups ? f0 + k * 16 : f0;
             const int64_t rest = k < n_groups ? (f0 + T - fk) * (int64_t)D * 4 : 0;
@@ -517,11 +531,13 @@ __global__ __launch_bounds__(256) void emission_utt_f32_kernel(
 #pragma unroll
             for (int q = 0; q < RQ; ++q)
                 dst[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off + 64u * q, 0, 0);
+            if constexpr (H != 0) dh = __builtin_amdgcn_raw_buffer_load_b64(rsrc, half_off, 0, 0);
         };
-        u32x4 xa[RQ], xb[RQ];
-        load(0, xa);
+        u32x4 xa[RQ ? RQ : 1], xb[RQ ? RQ : 1];
+        u32x2 ha = {0u, 0u}, hb = {0u, 0u};
+        load(0, xa, ha);
         for (int64_t k = 0; k < n_groups; ++k) {
-            load(k + 1, xb);
+            load(k + 1, xb, hb);
             f32x4 a1 = c0, a2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < RQ; ++q) {
@@ -530,6 +546,14 @@ __global__ __launch_bounds__(256) void emission_utt_f32_kernel(
                 for (int i = 0; i < 4; ++i) {
                     a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[q][i], x[i], a1, 0, 0, 0);
                     a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[q][i], x[i] * x[i], a2, 0, 0, 0);
+                }
+            }
+            if constexpr (H != 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float x = __uint_as_float(ha[i]);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh1[i], x, a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh2[i], x * x, a2, 0, 0, 0);
                 }
             }
             const int64_t t = k * 16 + ul;
@@ -547,6 +571,7 @@ __global__ __launch_bounds__(256) void emission_utt_f32_kernel(
             }
 #pragma unroll
             for (int q = 0; q < RQ; ++q) xa[q] = xb[q];
+            ha = hb;
         }
     }
 }
@@ -645,25 +670,26 @@ int srx_mfma_emission_utt_f32(srx_context* h, const void* X, const int64_t* off,
                               float* out, hipStream_t st) {
     const int M = md->n_models, S = md->n_states, D = md->n_features;
     if (S > 16 || D > 48 || M > 4096 || n_frames <= 0 || U <= 0) return SRX_EUNSUPPORTED;
-    const int RQ = (D + 15) / 16;
-    const size_t n_w = (size_t)M * 16 * RQ * 32, n_c = (size_t)M * 16;
+    const int H = (D % 16 >= 1 && D % 16 <= 8) ? 1 : 0;
+    const int RQ = H ? D / 16 : (D + 15) / 16;
+    const size_t n_w = (size_t)M * 16 * (RQ * 32 + H * 16), n_c = (size_t)M * 16;
     float* base;
     int rc = srx_ws_ensure(h, WS_MISC, 4 * (n_w + n_c), (void**)&base);
     if (rc) return rc;
     float* cst = base + n_w;
-    hipLaunchKernelGGL(emission_f32_prep_kernel, dim3(16), dim3(256), 0, st, *md, RQ, base, cst);
+    hipLaunchKernelGGL(emission_f32_prep_kernel, dim3(16), dim3(256), 0, st, *md, RQ, H, base, cst);
     int64_t gx = (U + 3) / 4;
     const int64_t cap = (int64_t)h->n_cu * 8;
     if (gx > cap) gx = cap;
     const float* Xf = (const float*)X;
-#define SRX_CASE(rq)                                                                        \
-    if (RQ == rq) {                                                                         \
-        hipLaunchKernelGGL((emission_utt_f32_kernel<rq>), dim3((unsigned)gx), dim3(256), 0, \
-                           st, Xf, off, U, n_frames, utt_model, S, D, base, cst, out);      \
-        SRX_HIP(hipGetLastError());                                                         \
-        return SRX_OK;                                                                      \
+#define SRX_CASE(rq, hh)                                                                        \
+    if (RQ == rq && H == hh) {                                                                  \
+        hipLaunchKernelGGL((emission_utt_f32_kernel<rq, hh>), dim3((unsigned)gx), dim3(256), 0, \
+                           st, Xf, off, U, n_frames, utt_model, S, D, base, cst, out);          \
+        SRX_HIP(hipGetLastError());                                                             \
+        return SRX_OK;                                                                          \
     }
-    SRX_CASE(3) SRX_CASE(2) SRX_CASE(1)
+    SRX_CASE(0, 1) SRX_CASE(1, 0) SRX_CASE(1, 1) SRX_CASE(2, 0) SRX_CASE(2, 1) SRX_CASE(3, 0)
 #undef SRX_CASE
     return SRX_EUNSUPPORTED;
 }
