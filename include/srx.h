@@ -131,8 +131,7 @@ int srx_destroy(srx_handle_t h);
  * SRX_STATS_ALL (0, default) or SRX_STATS_TRANSITIONS (1) -- nobs, logprob, start and trans
  * only, what the reference's own fit() re-estimates from (do_em_mstep, my_hmmlearn/hmm.py:237-253;
  * srx_mstep in SRX_MSTEP_TRANSITIONS_ONLY mode).  The post, obs and obs2 entries of the records
- * are then either complete or all zero: the float32 kernels (and the float64 ones of small
- * jobs) leave out their pass over the features, the others compute everything as before. */
+ * are then all zero: the kernels leave out their pass over the features. */
 enum srx_option { SRX_OPT_EXACT_F32 = 1, SRX_OPT_ESTEP_PATH = 2, SRX_OPT_VITERBI_PATH = 3,
                   SRX_OPT_ESTEP_STATS = 4 };
 enum srx_estep_stats { SRX_STATS_ALL = 0, SRX_STATS_TRANSITIONS = 1 };

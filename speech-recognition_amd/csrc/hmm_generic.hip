@@ -1810,7 +1810,11 @@ int estep_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_
 #define OBS(SL)                                                                                   \
     hipLaunchKernelGGL((obs_stats_kernel<T, SL>), dim3(g_obs), dim3(kBlock), 0, st, (const T*)X,  \
                        (const T*)lat, off, U, utt_model, utt_order, M, S, D, part_obs)
-    if (obs_mfma) {
+    // (a caller that re-estimates start and transition probabilities only gets zeros for
+    // the sums over the features: no pass over X)
+    const bool with_obs = h->estep_stats != SRX_STATS_TRANSITIONS;
+    if (!with_obs) {
+    } else if (obs_mfma) {
         rc = srx_mfma_obs_stats_f64(h, X, lat, off, U, utt_model, utt_order, md, part_obs, g_obs, st);
         if (rc) return rc;
     } else if (slots <= 1) OBS(1);
@@ -1823,7 +1827,7 @@ int estep_t(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_
     const int64_t n_out = (int64_t)M * (P + Q);                  // one wave per output sum
     const int g_red = (int)std::min<int64_t>((n_out * 64 + kBlock - 1) / kBlock, 4096);
     hipLaunchKernelGGL(reduce_stats_kernel, dim3(g_red), dim3(kBlock), 0, st, (const double*)part, g_fb,
-                       (const double*)part_obs, g_obs, M, S, D, out_stats);
+                       (const double*)part_obs, with_obs ? g_obs : 0, M, S, D, out_stats);
     SRX_HIP(hipGetLastError());
     return SRX_OK;
 }

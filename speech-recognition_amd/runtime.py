@@ -80,7 +80,7 @@ class Context:
         """What the caller of the E-step will use: "all" statistics or "transitions" (count,
         log-probability, start and transition sums: what the reference's own fit()
         re-estimates from, my_hmmlearn/hmm.py:237-253).  With "transitions" the sums over the
-        features come back complete or all zero; small jobs skip their pass over X."""
+        features come back zero: the kernels leave out their pass over X."""
         code = {"all": _lib.SRX_STATS_ALL, "transitions": _lib.SRX_STATS_TRANSITIONS}[which]
         check(lib.srx_set_option(self._h, _lib.SRX_OPT_ESTEP_STATS, code), "srx_set_option")
 

@@ -885,7 +885,8 @@ def test_fused_estep_on_peaked_models(sra, ctx, S, D, spread, alpha, tol):
         np.testing.assert_allclose(g64[0][k], st[k], rtol=0, atol=1e-9 * max(1.0, np.abs(st[k]).max()))
 
 
-@pytest.mark.parametrize("dtype,path", [("float32", "auto"), ("float64", "auto"), ("float32", "fused")])
+@pytest.mark.parametrize("dtype,path", [("float32", "auto"), ("float64", "auto"), ("float32", "fused"),
+                                        ("float64", "fused")])
 def test_estep_for_a_transitions_only_mstep(sra, ctx, dtype, path):
     """SRX_OPT_ESTEP_STATS = transitions: count, log-probability, start and transition sums
     are the ones of the full E-step bit for bit, the sums over the features complete or all
@@ -912,7 +913,7 @@ def test_estep_for_a_transitions_only_mstep(sra, ctx, dtype, path):
     gf, gp = bank.unpack_stats(full), bank.unpack_stats(part)
     for m in range(M):
         assert gp[m]["nobs"] == gf[m]["nobs"]
-        if path == "fused":         # (its sums are float64 atomics: equal to rounding of the order)
+        if path == "fused":         # (sums by float64 atomics: equal to the rounding of their order)
             assert abs(gp[m]["logprob"] - gf[m]["logprob"]) <= 1e-12 * abs(gf[m]["logprob"])
             np.testing.assert_allclose(gp[m]["start"], gf[m]["start"], rtol=1e-12, atol=1e-300)
             np.testing.assert_allclose(gp[m]["trans"], gf[m]["trans"], rtol=1e-12, atol=1e-300)
