@@ -767,6 +767,18 @@ __global__ __launch_bounds__(256) void topdb_dct_kernel(const T* __restrict__ lo
     __shared__ T red[256];
     __shared__ T strip[4][128];
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    // The lane's share of its DCT row (the split of dct_rows, summed in the same order)
+    // stays in registers over all frames when it fits: n_mel a multiple of `parts`, at
+    // most 32 weights per lane and 128 filters.
+    int kp = 1;
+    while (kp < c.n_ceps) kp <<= 1;
+    const int parts = kWave / kp, k = lane / parts, part = lane % parts;
+    const int held_n = c.n_mel / parts;
+    const bool held = c.n_mel % parts == 0 && held_n <= 32 && c.n_mel <= 2 * kWave;
+    T w[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+        w[i] = held && i < held_n && k < c.n_ceps ? dct[(size_t)k * c.n_mel + part + i * parts] : (T)0;
     for (int64_t u = blockIdx.x; u < U; u += gridDim.x) {
         const int64_t n = so[u + 1] - so[u];
         const int64_t Tu = raw_frames(c, n);
@@ -784,14 +796,44 @@ __global__ __launch_bounds__(256) void topdb_dct_kernel(const T* __restrict__ lo
             __syncthreads();
         }
         const T thr = red[0] - top_db;
-        for (int64_t t = wave; t < Tu; t += 4) {
-            for (int q = lane; q < c.n_mel; q += kWave) {
-                const T v = lm[t * c.n_mel + q];
-                strip[wave][q] = v < thr ? thr : v;
+        if (held) {
+            // the row of frame t + 4 is requested before the sums of frame t
+            T nxt[2];
+            auto request = [&](int64_t t) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int q = lane + j * kWave;
+                    const int64_t tc = t < Tu ? t : Tu - 1;
+                    nxt[j] = lm[tc * c.n_mel + (q < c.n_mel ? q : c.n_mel - 1)];
+                }
+            };
+            request(wave);
+            for (int64_t t = wave; t < Tu; t += 4) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int q = lane + j * kWave;
+                    if (q < c.n_mel) strip[wave][q] = nxt[j] < thr ? thr : nxt[j];
+                }
+                request(t + 4);
+                wave_sync();
+                T acc = 0;
+#pragma unroll
+                for (int i = 0; i < 32; ++i)
+                    if (i < held_n) acc += w[i] * strip[wave][part + i * parts];
+                for (int o = parts >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
+                if (k < c.n_ceps && part == 0) cep[(row0 + t) * c.n_ceps + k] = acc;
+                wave_sync();
             }
-            wave_sync();
-            dct_rows<T>(dct, strip[wave], c.n_mel, c.n_ceps, lane, cep + (row0 + t) * c.n_ceps);
-            wave_sync();
+        } else {
+            for (int64_t t = wave; t < Tu; t += 4) {
+                for (int q = lane; q < c.n_mel; q += kWave) {
+                    const T v = lm[t * c.n_mel + q];
+                    strip[wave][q] = v < thr ? thr : v;
+                }
+                wave_sync();
+                dct_rows<T>(dct, strip[wave], c.n_mel, c.n_ceps, lane, cep + (row0 + t) * c.n_ceps);
+                wave_sync();
+            }
         }
         __syncthreads();                        // red of the next utterance
     }
