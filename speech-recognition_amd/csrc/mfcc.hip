@@ -96,11 +96,11 @@ __global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __res
     const int H = c.nfft >> 1;
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int n_waves = blockDim.x / kWave;
-    // per-wave LDS: H complex, H+1 power bins, n_mel log energies
-    const size_t per_wave = sizeof(T) * ((size_t)2 * H + (H + 1) + c.n_mel + 1);
+    // per-wave LDS: H complex, n_mel log energies.  The power bins take the place of the
+    // transform: bin k < H in the real slot of point k, bin H in the imaginary slot of point 0.
+    const size_t per_wave = (sizeof(T) * ((size_t)2 * H + c.n_mel + 1) + 15) & ~(size_t)15;
     cplx<T>* z = (cplx<T>*)(smem_raw + per_wave * wave);
-    T* pw = (T*)(z + H);
-    T* lm = pw + (H + 1);
+    T* lm = (T*)(z + H);
 
     const int64_t chunk = (int64_t)kChunkFrames * c.hop;
     const int64_t n_chunks = (total + chunk - 1) / chunk;
@@ -201,18 +201,44 @@ __global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __res
                     }
                     wave_sync();
                 }
-                // ---- unpack to the real-input spectrum, power / nfft
+                // ---- unpack to the real-input spectrum, power / nfft.  Bins k and H - k come
+                // from the same two points, so a lane takes the pair and leaves the two powers
+                // where it read the points: no other lane touches them.  Four pairs at a time,
+                // all loads before the first store, so that the loads are in flight together.
                 const T inv_n = (T)c.power_scale;
-#pragma unroll 4
-                for (int k = lane; k <= H; k += kWave) {
-                    const cplx<T> zk = z[k & (H - 1)];
-                    const cplx<T> zc = z[(H - k) & (H - 1)];
+                auto power = [&](const cplx<T>& zk, const cplx<T>& zc, const cplx<T>& w) -> T {
                     const T er = (T)0.5 * (zk.re + zc.re), ei = (T)0.5 * (zk.im - zc.im);
                     const T orr = (T)0.5 * (zk.im + zc.im), oi = (T)-0.5 * (zk.re - zc.re);
-                    const cplx<T> w = tw[k];
                     const T xr = er + w.re * orr - w.im * oi;
                     const T xi = ei + w.re * oi + w.im * orr;
-                    pw[k] = (xr * xr + xi * xi) * inv_n;
+                    return (xr * xr + xi * xi) * inv_n;
+                };
+                for (int k0 = 0; k0 <= (H >> 1); k0 += 4 * kWave) {
+                    cplx<T> zk[4], zc[4], wk[4], wc[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int k = k0 + j * kWave + lane;
+                        k = k <= (H >> 1) ? k : (H >> 1);
+                        zk[j] = z[k];
+                        zc[j] = z[(H - k) & (H - 1)];
+                        wk[j] = tw[k];
+                        wc[j] = tw[H - k];
+                    }
+                    T pa[4], pb[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        pa[j] = power(zk[j], zc[j], wk[j]);
+                        pb[j] = power(zc[j], zk[j], wc[j]);
+                    }
+                    wave_sync();                // (clamped lanes re-read the middle pair)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = k0 + j * kWave + lane;
+                        if (k > (H >> 1)) continue;
+                        z[k].re = pa[j];
+                        if (k == 0) z[0].im = pb[j];
+                        else z[H - k].re = pb[j];
+                    }
                 }
                 wave_sync();
                 // ---- mel triangles (CSR), exact zeros -> eps, log_mult * log10
@@ -224,7 +250,10 @@ __global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __res
                     const int m = m0 + ((rnd & 1) ? cnt - 1 - lane : lane);
                     T e = 0;
 #pragma unroll 4
-                    for (int q = c.mel_ptr[m]; q < c.mel_ptr[m + 1]; ++q) e += pw[c.mel_bin[q]] * mel_w[q];
+                    for (int q = c.mel_ptr[m]; q < c.mel_ptr[m + 1]; ++q) {
+                        const int bin = c.mel_bin[q];
+                        e += ((const T*)z)[bin < H ? 2 * bin : 1] * mel_w[q];
+                    }
                     if (c.log_floor > 0.0) e = e < (T)c.log_floor ? (T)c.log_floor : e;
                     else if (e == (T)0) e = (T)2.220446049250313e-16;   // np.finfo(float).eps, mfcc.py:43
                     lm[m] = (T)c.log_mult * log10(e);
@@ -1210,9 +1239,16 @@ int srx_mfcc_batch(srx_handle_t h, srx_mfcc_plan_t p, const void* audio, int dty
         rc = srx_ws_ensure(h, WS_LOGLIK, esz * (size_t)rows * c.n_mel, &d.logmel);
         if (rc) return rc;
     }
-    const size_t per_wave = esz * ((size_t)2 * H + (H + 1) + c.n_mel + 1);
-    int waves = 4;
-    while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
+    const size_t per_wave = (esz * ((size_t)2 * H + c.n_mel + 1) + 15) & ~(size_t)15;
+    // waves per workgroup: the count that leaves the most waves on a CU's 160 KB of LDS
+    // within the 64 KB a workgroup may take (long transforms are bound by LDS, not registers)
+    int waves = 1, best = 0;
+    for (int w = 1; w <= 8; ++w) {
+        if (per_wave * w > 64 * 1024) break;
+        int per_cu = (int)(160 * 1024 / (per_wave * w)) * w;
+        per_cu = per_cu > 32 ? 32 : per_cu;
+        if (per_cu > best || (per_cu == best && w <= 4)) { best = per_cu; waves = w; }
+    }
     SRX_REQUIRE(per_wave * waves <= 64 * 1024, "srx_mfcc_batch: nfft %d needs %zu bytes of LDS",
                 c.nfft, per_wave);
     const int64_t chunk = (int64_t)kChunkFrames * c.hop;
