@@ -126,7 +126,10 @@ __global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __res
             const int64_t row0 = v0 / c.hop;   // first cepstra row of this utterance
             for (int64_t t = ta; t < tb; ++t, ++item) {
                 if (item % n_waves != wave) continue;
-                const T* x = audio + s0 + t * c.hop;
+                // (a centred frame that lies inside its utterance needs no padding: it is
+                // read like an uncentred frame that starts half a transform earlier)
+                const bool padded = c.center && (t * c.hop < H || t * c.hop - H + c.nfft > n);
+                const T* x = audio + s0 + t * c.hop - (c.center ? H : 0);
                 // ---- load, window, pack even/odd samples, bit-reversed store
                 // (the loops of this kernel are unrolled by 4 so that the global and LDS
                 // loads of four iterations are in flight together: one at a time, every
@@ -135,7 +138,7 @@ __global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __res
                 for (int k = lane; k < H; k += kWave) {
                     const int n0 = 2 * k, n1 = 2 * k + 1;
                     cplx<T> v;
-                    if (c.center) {
+                    if (padded) {
                         // sample i of the frame is signal sample t*hop - nfft/2 + i
                         auto at = [&](int i) -> T {
                             int64_t j = t * c.hop - H + i;
