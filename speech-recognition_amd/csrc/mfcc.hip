@@ -178,6 +178,22 @@ __global__ void cepstra_kernel(const T* __restrict__ audio, const int64_t* __res
                     wave_sync();
                     s0st = 1;
                 }
+                if (s0st == 0 && c.log2h >= 2) {
+                    // the first radix-4 pass has twiddles 1 and -i only: no table, no products
+#pragma unroll 4
+                    for (int q = lane; q < (H >> 2); q += kWave) {
+                        const int i0 = q << 2;
+                        const cplx<T> x0 = z[i0], x1 = z[i0 + 1], x2 = z[i0 + 2], x3 = z[i0 + 3];
+                        const T a0r = x0.re + x1.re, a0i = x0.im + x1.im, a1r = x0.re - x1.re, a1i = x0.im - x1.im;
+                        const T a2r = x2.re + x3.re, a2i = x2.im + x3.im, a3r = x2.re - x3.re, a3i = x2.im - x3.im;
+                        z[i0].re = a0r + a2r;     z[i0].im = a0i + a2i;
+                        z[i0 + 1].re = a1r + a3i; z[i0 + 1].im = a1i - a3r;
+                        z[i0 + 2].re = a0r - a2r; z[i0 + 2].im = a0i - a2i;
+                        z[i0 + 3].re = a1r - a3i; z[i0 + 3].im = a1i + a3r;
+                    }
+                    wave_sync();
+                    s0st = 2;
+                }
                 for (int s = s0st; s < c.log2h; s += 2) {
                     const int half = 1 << s;
                     const int ts1 = c.nfft >> (s + 1), ts2 = c.nfft >> (s + 2);
