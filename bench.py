@@ -165,6 +165,9 @@ def main():
                     help="utterances of the workload the CPU baseline is timed on (about 15 s)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the audio -> label chain line")
+    ap.add_argument("--pipeline-utts", type=int, default=65536,
+                    help="recordings (3 s each) of the audio -> label chain line")
     ap.add_argument("--no-large", action="store_true", help="skip the large-model (1024-state GMM) lines")
     ap.add_argument("--large-utts", type=int, default=4096)
     ap.add_argument("--train-utts", type=int, default=0,
@@ -173,6 +176,9 @@ def main():
     ap.add_argument("--prewarm", type=int, default=150,
                     help="untimed passes before the warm-up steps that bring the clock to its steady state")
     ap.add_argument("--no-train", action="store_true", help="skip the Baum-Welch measurement")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="N > 1: skip the comparison of the all-reduced statistics with rank 0's "
+                         "E-step over all ranks' utterances")
     ap.add_argument("--all-extra", action="store_true",
                     help="run the secondary extra lines on more than one GPU too")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL)")
@@ -427,6 +433,52 @@ def main():
                          "flop_per_frame_executed": flop_per_frame,
                          "vector_peak_frac": raw_frames * flop_per_frame / dtf / 157.3e12,
                          "config": "16 kHz, 400/160 samples, 512-pt FFT, 40 mel, 13 MFCC+d+dd, z-score"}
+        # The whole chain the reference's recognize runs per file (HMM_final.py:49-52, :18-23), for
+        # 65,536 recordings at once and with nothing leaving the device: audio -> 39-dim features
+        # (the front-end above) -> scores against the 6 x 8-state bank -> label (arg max).
+        if not args.no_pipeline:
+            n_utt_p = args.pipeline_utts
+            audio_p = torch.empty((n_utt_p * n_samp,), device=dev, dtype=torch.float32)
+            for i0 in range(0, audio_p.numel(), 1 << 28):
+                audio_p[i0:i0 + (1 << 28)].normal_(generator=g2).mul_(0.2)
+            so_p = np.arange(0, (n_utt_p + 1) * n_samp, n_samp, dtype=np.int64)
+            plan_p = sra.MfccPlan(ctx, 16000, nfft=512, n_mel=40, delta_order=2, zscore=True)
+            data_p = plan_p.run_ragged(audio_p, so_p)
+            feats_p = data_p.X
+            lab_p, sc_p = bank.classify(data_p)
+
+            def chain():
+                d = plan_p.run_ragged(audio_p, so_p, out=feats_p)
+                return bank.classify(d, scores=sc_p, labels=lab_p)
+
+            def timed(fn, n):
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                barrier()
+                return (time.perf_counter() - t0) / n
+
+            warm_gpu(chain, ms=100.0)
+            dt_chain = timed(chain, 5)
+            dt_fe = timed(lambda: plan_p.run_ragged(audio_p, so_p, out=feats_p), 5)
+            dt_sc = timed(lambda: bank.score(data_p, out=sc_p), 5)
+            dt_am = timed(lambda: sra.argmax_scores(ctx, sc_p, out=lab_p), 5)
+            n_fr_p = int(data_p.n_frames)
+            hist = torch.bincount(lab_p.long(), minlength=N_MODELS).cpu().tolist()
+            extra["pipeline"] = {
+                "utterances_per_s": n_utt_p * world / dt_chain, "frames_per_s": n_fr_p * world / dt_chain,
+                "audio_seconds_per_s": n_utt_p * 3.0 * world / dt_chain, "ms": dt_chain * 1e3,
+                "stage_ms": {"front_end": dt_fe * 1e3, "scoring": dt_sc * 1e3, "argmax": dt_am * 1e3},
+                "stage_share": {"front_end": dt_fe / dt_chain, "scoring": dt_sc / dt_chain,
+                                "argmax": dt_am / dt_chain},
+                "hbm_frac": (n_utt_p * n_samp * 4 + n_utt_p * 4) / dt_chain / 1e9 / HBM_PEAK_GBS,
+                "label_histogram": hist,
+                "config": f"{n_utt_p} recordings x 3 s at 16 kHz (float32, resident) -> 13 MFCC+d+dd, z-score "
+                          f"({n_fr_p // n_utt_p} frames each) -> 6 x 8-state scores -> int32 label; "
+                          "algorithmic bytes: 4 B per sample in + 4 B per recording out"}
+            del audio_p, data_p, feats_p, lab_p, sc_p, plan_p
+            torch.cuda.empty_cache()
         # the reference's other front-end (extract_mfcc, HMM_lib.py:11-15): librosa's conventions,
         # 2048-point transform every 512 samples, 128 Slaney filters, top_db clamp, 13 cepstra,
         # z-score; the same buffer read as 22.05 kHz audio
@@ -573,6 +625,37 @@ def main():
             dt3 = float(t.item())
         dt3 /= iters
         del tr3, bank3
+        # The sharded E-step against the unsharded one: every rank's statistics of one E-step
+        # from the initial parameters, summed by the all-reduce, beside rank 0's E-step over
+        # all ranks' utterances in one launch (their features regenerated from the ranks' seeds).
+        stats_err = None
+        if world > 1 and not args.no_verify:
+            bank4 = sra.HMMBank(ctx, sp2, A2, mu2, cv2)
+            um_t = ctx.tensor((np.arange(Ut) % N_MODELS).astype(np.int32))
+            st_sum = sra.parallel.allreduce_stats(bank4.estep(dt_, um_t).clone())
+            if rank == 0:
+                Xall = torch.empty((world * Ut * T_FRAMES, N_FEAT), device=dev, dtype=torch.float32)
+                for r in range(world):
+                    gr = torch.Generator(device=dev)
+                    gr.manual_seed(4321 + r)
+                    part = Xall[r * Ut * T_FRAMES:(r + 1) * Ut * T_FRAMES]
+                    for i0 in range(0, Ut * T_FRAMES, 1 << 24):
+                        part[i0:i0 + (1 << 24)].normal_(generator=gr)
+                offa = torch.arange(0, (world * Ut + 1) * T_FRAMES, T_FRAMES, device=dev, dtype=torch.int64)
+                um_a = ctx.tensor(np.tile(np.arange(Ut) % N_MODELS, world).astype(np.int32))
+                st_one = bank4.estep(sra.Ragged(ctx, Xall, offsets=offa, dtype="float32"), um_a)
+                # largest difference relative to the largest entry of its own array (count,
+                # log-probability, start, trans, post, obs, obs2 of each model)
+                S2 = 16
+                cuts = np.cumsum([0, 1, 1, S2, S2 * S2, S2, S2 * N_FEAT, S2 * N_FEAT])
+                stats_err = 0.0
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    seg_one, seg_sum = st_one[:, a:b], st_sum[:, a:b]
+                    scale = seg_one.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
+                    stats_err = max(stats_err, float(((seg_sum - seg_one).abs() / scale).max().item()))
+                del Xall, st_one
+            barrier()
+        out["sharded_vs_single_rank_stats_max_rel_err"] = stats_err
         out["baum_welch_iter_per_s"] = 1.0 / dtt
         out["allreduce_ms_per_iter"] = ar_ms
         out["rccl_ranks"] = ranks_seen

@@ -126,14 +126,13 @@ int srx_destroy(srx_handle_t h);
  * and at most 48 features: SRX_VITERBI_AUTO (0, default) and SRX_VITERBI_FUSED (1) decode in
  * one kernel that keeps the log-densities on the chip (it measured faster than the other path
  * at every batch size from 128 utterances up), SRX_VITERBI_SPLIT (2) in two (log-densities to
- * memory, then the recursion; tests, timing).  Same states and log-probabilities, bit for bit.
- * SRX_OPT_ESTEP_STATS says which statistics the caller of srx_estep_stats will use:
- * SRX_STATS_ALL (0, default) or SRX_STATS_TRANSITIONS (1) -- nobs, logprob, start and trans
- * only, what the reference's own fit() re-estimates from (do_em_mstep, my_hmmlearn/hmm.py:237-253;
- * srx_mstep in SRX_MSTEP_TRANSITIONS_ONLY mode).  The post, obs and obs2 entries of the records
- * are then all zero: the kernels leave out their pass over the features. */
-enum srx_option { SRX_OPT_EXACT_F32 = 1, SRX_OPT_ESTEP_PATH = 2, SRX_OPT_VITERBI_PATH = 3,
-                  SRX_OPT_ESTEP_STATS = 4 };
+ * memory, then the recursion; tests, timing).  Same states and log-probabilities, bit for bit. */
+enum srx_option { SRX_OPT_EXACT_F32 = 1, SRX_OPT_ESTEP_PATH = 2, SRX_OPT_VITERBI_PATH = 3 };
+/* Which statistics a caller of srx_estep_stats_select will use: SRX_STATS_ALL (0) or
+ * SRX_STATS_TRANSITIONS (1) -- nobs, logprob, start and trans only, what the reference's own
+ * fit() re-estimates from (do_em_mstep, my_hmmlearn/hmm.py:435-451; srx_mstep in
+ * SRX_MSTEP_TRANSITIONS_ONLY mode).  The post, obs and obs2 entries of the records are then
+ * all zero: the kernels leave out their pass over the features. */
 enum srx_estep_stats { SRX_STATS_ALL = 0, SRX_STATS_TRANSITIONS = 1 };
 enum srx_estep_path { SRX_ESTEP_AUTO = 0, SRX_ESTEP_FUSED = 1, SRX_ESTEP_LANE = 2 };
 enum srx_viterbi_path { SRX_VITERBI_AUTO = 0, SRX_VITERBI_FUSED = 1, SRX_VITERBI_SPLIT = 2 };
@@ -219,6 +218,14 @@ int srx_forward_score_generic(srx_handle_t h, const void* X, int dtype,
                               const int64_t* utt_offsets, int64_t n_utts, int64_t n_frames,
                               const srx_models_t* models, double* out_scores, void* stream);
 
+/* ---- classification: the label step of recognize, max(scores, key=scores.get)
+ * (HMM_final.py:51-52; recognize_lib, HMM_final.py:54-57, HMM_lib.py:50-53), for every row of a
+ * score matrix on the device: out_labels[u] (int32) is the first column of scores[u, 0..n_models)
+ * whose value is larger than every earlier column's -- on ties the first model in the
+ * caller's order wins, as the first key of the reference's dict does. */
+int srx_argmax_scores(srx_handle_t h, const double* scores, int64_t n_utts, int32_t n_models,
+                      int32_t* out_labels, void* stream);
+
 /* Allocation-free variant of srx_forward_score (same arguments, same results, SRX_F32
  * only).  It has no counterpart in the reference: it is for callers that cannot allocate
  * device memory while they run -- code under HIP graph capture, tight serving loops,
@@ -230,7 +237,13 @@ int srx_forward_score_generic(srx_handle_t h, const void* X, int dtype,
  * array (about 40 sixteen-row tiles: 80 models of 8 states, 40 of 16 states at 39
  * features); anything else returns SRX_EUNSUPPORTED or, for a bank that is too large,
  * SRX_EINVAL with the sizes in srx_last_error().  All contexts of one GPU share the
- * array: two calls that overlap on one GPU (two streams, two threads) race on it. */
+ * array.  Calls of one process are put in order by the library: a call on another stream
+ * than the previous one makes its stream wait for the previous call's kernels (one event per
+ * GPU; the array is looked up with hipGetSymbolAddress in srx_create or, failing that, at the
+ * first call, which then returns SRX_EHIP if the lookup fails again).  Not ordered: calls
+ * made while their stream is under graph capture, and therefore the launches of such graphs
+ * (their owner keeps two of them from overlapping on one GPU), and calls of other processes
+ * (each process has its own array). */
 int srx_forward_score_static(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
                              int64_t n_utts, int64_t n_frames, const srx_models_t* models,
                              double* out_scores, void* stream);
@@ -298,6 +311,13 @@ int srx_estep_stats(srx_handle_t h, const void* X, int dtype, const int64_t* utt
                     const int64_t* utt_order, const srx_models_t* models, double* out_stats,
                     void* stream);
 
+/* The same with the statistics the caller will read named per call (enum srx_estep_stats):
+ * srx_estep_stats is this with SRX_STATS_ALL. */
+int srx_estep_stats_select(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
+                           int64_t n_utts, int64_t n_frames, const int32_t* utt_model,
+                           const int64_t* utt_order, const srx_models_t* models, int which_stats,
+                           double* out_stats, void* stream);
+
 /* Same contract, always through the shape-generic kernels. */
 int srx_estep_stats_generic(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
                             int64_t n_utts, int64_t n_frames, const int32_t* utt_model,
@@ -313,6 +333,13 @@ int srx_estep_stats_generic(srx_handle_t h, const void* X, int dtype, const int6
  * first call and enqueues ncclAllReduce(stats, stats, count, ncclDouble, ncclSum) on the
  * stream.  In place; `count` doubles (n_models * srx_stats_size). */
 int srx_allreduce_stats(srx_handle_t h, void* nccl_comm, double* stats, int64_t count, void* stream);
+
+/* ---- set-up of a fit: what MyGaussianHMM.init takes from the training frames besides
+ * the rows it picks as means (my_hmmlearn/hmm.py:130-132): per feature column the mean and
+ * the variance with one degree of freedom taken off (the diagonal of np.cov(X.T)), in float64
+ * whatever the dtype of X[n_frames, n_features].  out_mean / out_var: n_features doubles. */
+int srx_column_moments(srx_handle_t h, const void* X, int dtype, int64_t n_frames, int32_t n_features,
+                       double* out_mean, double* out_var, void* stream);
 
 /* ---- M-step: do_em_mstep (hmm.py:435-451) and do_mstep (hmm.py:165-184),
  * applied in place to every model of the bank from its statistics record. */

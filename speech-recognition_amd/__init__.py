@@ -11,7 +11,8 @@ include/srx.h); importing the package fails if that library is not built.
 from . import _lib                      # noqa: F401  (raises if libsrx.so is missing)
 from . import runtime, hmm, mfcc, endpoint, recognizer, hmm_lib, parallel, SpeechUtil   # noqa: F401
 from .hmm import MyGaussianHMM, GaussianHMM, ConvergenceMonitor        # noqa: F401
-from .runtime import Context, HMMBank, Ragged, MfccPlan, GmmEmission, viterbi_dense   # noqa: F401
+from .runtime import (Context, HMMBank, Ragged, MfccPlan, GmmEmission, viterbi_dense,   # noqa: F401
+                      argmax_scores, column_moments)
 
 HMM_final = recognizer   # the reference's module name for the same functions
 HMM_lib = hmm_lib         # likewise (librosa-convention features, hmmlearn-style models)

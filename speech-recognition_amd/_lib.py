@@ -20,7 +20,6 @@ SRX_OPT_EXACT_F32 = 1
 SRX_OPT_ESTEP_PATH = 2
 SRX_OPT_VITERBI_PATH = 3
 SRX_VITERBI_AUTO, SRX_VITERBI_FUSED, SRX_VITERBI_SPLIT = 0, 1, 2
-SRX_OPT_ESTEP_STATS = 4
 SRX_STATS_ALL, SRX_STATS_TRANSITIONS = 0, 1
 SRX_ESTEP_AUTO, SRX_ESTEP_FUSED, SRX_ESTEP_LANE = 0, 1, 2
 SRX_EINVAL, SRX_EHIP, SRX_ENOMEM, SRX_EUNSUPPORTED = -1, -2, -3, -4
@@ -89,8 +88,11 @@ SIGNATURES = {
     "srx_static_scratch_bytes": (_i64, []),
     "srx_viterbi": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, _vp, C.POINTER(Models), _vp, _vp, _vp]),
     "srx_estep_stats": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, _vp, _vp, C.POINTER(Models), _vp, _vp]),
+    "srx_estep_stats_select": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, _vp, _vp, C.POINTER(Models), C.c_int, _vp, _vp]),
     "srx_estep_stats_generic": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, _vp, _vp, C.POINTER(Models), _vp, _vp]),
     "srx_allreduce_stats": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "srx_argmax_scores": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "srx_column_moments": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _vp, _vp, _vp]),
     "srx_mstep": (C.c_int, [_vp, _vp, C.POINTER(Priors), C.c_int, C.POINTER(Models), _vp]),
     "srx_gmm_emission_loglik": (C.c_int, [_vp, _vp, C.c_int, _i64, C.POINTER(Gmm), _vp, _vp]),
     "srx_posteriors": (C.c_int, [_vp, _vp, C.c_int, _vp, _i64, _i64, _vp, C.POINTER(Models), _vp, _vp, _vp]),

@@ -15,27 +15,36 @@ thread_local char g_err[512] = "";
 
 // Table memory of srx_forward_score_static: a fixed device array instead of the
 // context's hipMalloc'ed workspace, for callers that must not allocate.  Every GPU
-// holds its own copy at its own address; the address is looked up once per device
-// in srx_create (the array's name is only a host-side handle for that lookup and is
-// never passed to a kernel or a memory routine).
+// holds its own copy at its own address; the address is looked up at the first static
+// call on a device (the array's name is only a host-side handle for that lookup and is
+// never passed to a kernel or a memory routine).  All contexts and streams of a GPU share
+// the array, so its users are put in order: a call on another stream than the last one
+// first makes its stream wait for an event recorded behind the last call's kernels.
 constexpr size_t kStaticScratchBytes = 256 * 1024;
 constexpr int kMaxDevices = 64;
 static __device__ __align__(256) __attribute__((used)) unsigned char scratch[kStaticScratchBytes];
-void* g_scratch_ptr[kMaxDevices] = {};
+struct StaticScratch {
+    void* ptr = nullptr;
+    hipEvent_t done = nullptr;       // behind the kernels of the last call that was not captured
+    hipStream_t last = nullptr;
+    bool recorded = false;
+};
+StaticScratch g_scratch[kMaxDevices];
 std::mutex g_scratch_mutex;
 
-// With `device` current: the address of this device's copy of `scratch`.
-int static_scratch_for(int device, void** out) {
+// With `device` current and g_scratch_mutex held: this device's entry, its address looked up.
+int static_scratch_for(int device, StaticScratch** out) {
     SRX_REQUIRE(device >= 0 && device < kMaxDevices, "device %d: at most %d devices are supported",
                 device, kMaxDevices);
-    std::lock_guard<std::mutex> lock(g_scratch_mutex);
-    if (!g_scratch_ptr[device]) {
+    StaticScratch& s = g_scratch[device];
+    if (!s.ptr) {
         void* p = nullptr;
         SRX_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
         SRX_REQUIRE(p != nullptr, "hipGetSymbolAddress returned a NULL address for device %d", device);
-        g_scratch_ptr[device] = p;
+        SRX_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        s.ptr = p;
     }
-    *out = g_scratch_ptr[device];
+    *out = &s;
     return SRX_OK;
 }
 }
@@ -116,14 +125,21 @@ int srx_create(int device, srx_handle_t* out) {
                       prop.gcnArchName);
         return SRX_EUNSUPPORTED;
     }
-    void* sp = nullptr;
-    int rc = static_scratch_for(device, &sp);
-    if (rc) return rc;
+    {
+        // The fixed table array of srx_forward_score_static is looked up here when it can be,
+        // so that the first static call (possibly under graph capture) finds it done; a
+        // failure is not this call's: that entry point tries again and reports it.
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        StaticScratch* ss = nullptr;
+        if (static_scratch_for(device, &ss) != SRX_OK) {
+            (void)hipGetLastError();
+            g_err[0] = 0;
+        }
+    }
     srx_context* h = new srx_context();
     memset(h, 0, sizeof(*h));
     h->device = device;
     h->n_cu = prop.multiProcessorCount;
-    h->static_scratch = sp;
     *out = h;
     return SRX_OK;
 }
@@ -148,10 +164,6 @@ int srx_set_option(srx_handle_t h, int option, int value) {
         case SRX_OPT_VITERBI_PATH:
             SRX_REQUIRE(value >= SRX_VITERBI_AUTO && value <= SRX_VITERBI_SPLIT, "srx_set_option: unknown Viterbi path %d", value);
             h->viterbi_path = value;
-            return SRX_OK;
-        case SRX_OPT_ESTEP_STATS:
-            SRX_REQUIRE(value == SRX_STATS_ALL || value == SRX_STATS_TRANSITIONS, "srx_set_option: unknown statistics selection %d", value);
-            h->estep_stats = value;
             return SRX_OK;
         default: srx_set_error("srx_set_option: unknown option %d", option); return SRX_EINVAL;
     }
@@ -304,8 +316,26 @@ int srx_forward_score_static(srx_handle_t h, const void* X, int dtype, const int
     SRX_REQUIRE(out_scores != nullptr, "srx_forward_score_static: NULL out_scores");
     SRX_REQUIRE(n_frames > 0, "srx_forward_score_static: no frames");
     SRX_HIP(hipSetDevice(h->device));
+    // One call at a time per process queues work on the array; across streams the order on
+    // the GPU follows from the event.  A stream under capture is left alone (an event
+    // recorded outside the capture cannot be waited for inside it, and one recorded inside
+    // says nothing about the graph's later launches): graphs that use this entry point on
+    // one GPU have to be ordered by their owner.
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    StaticScratch* ss = nullptr;
+    if ((rc = static_scratch_for(h->device, &ss))) return rc;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    SRX_HIP(hipStreamIsCapturing((hipStream_t)stream, &cap));
+    const bool eager = cap == hipStreamCaptureStatusNone;
+    if (eager && ss->recorded && ss->last != (hipStream_t)stream)
+        SRX_HIP(hipStreamWaitEvent((hipStream_t)stream, ss->done, 0));
     rc = srx_mfma_score_tables(h, X, utt_offsets, n_utts, n_frames, models, out_scores,
-                               h->static_scratch, kStaticScratchBytes, (hipStream_t)stream);
+                               ss->ptr, kStaticScratchBytes, (hipStream_t)stream);
+    if (eager && rc == SRX_OK) {
+        SRX_HIP(hipEventRecord(ss->done, (hipStream_t)stream));
+        ss->last = (hipStream_t)stream;
+        ss->recorded = true;
+    }
     if (rc == SRX_EUNSUPPORTED)
         srx_set_error("srx_forward_score_static: no allocation-free kernel for n_models=%d n_states=%d "
                       "n_features=%d", models->n_models, models->n_states, models->n_features);
@@ -400,12 +430,17 @@ int srx_viterbi_dense(srx_handle_t h, const void* loglik, int dtype, const int64
 static int estep_common(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
                         int64_t n_utts, int64_t n_frames, const int32_t* utt_model,
                         const int64_t* utt_order, const srx_models_t* models, double* out_stats,
-                        void* stream, bool allow_fused, const char* who) {
+                        void* stream, bool allow_fused, int which_stats, const char* who) {
     int rc = check_common(h, X, dtype, n_utts, n_frames, utt_offsets, who);
     if (rc) return rc;
     if ((rc = check_models(models, who))) return rc;
     SRX_REQUIRE(out_stats != nullptr, "%s: NULL out_stats", who);
+    SRX_REQUIRE(which_stats == SRX_STATS_ALL || which_stats == SRX_STATS_TRANSITIONS,
+                "%s: unknown statistics selection %d", who, which_stats);
     SRX_HIP(hipSetDevice(h->device));
+    // (a property of this call, not of the context: every E-step call writes it before any
+    // kernel of that call is chosen, and nothing else reads it)
+    h->estep_stats = which_stats;
     if (allow_fused && dtype == SRX_F32) {
         // small jobs first: one lane per utterance beats a matrix-core wave they cannot fill
         if (h->estep_path != SRX_ESTEP_FUSED) {
@@ -431,7 +466,15 @@ int srx_estep_stats(srx_handle_t h, const void* X, int dtype, const int64_t* utt
                     const int64_t* utt_order, const srx_models_t* models, double* out_stats,
                     void* stream) {
     return estep_common(h, X, dtype, utt_offsets, n_utts, n_frames, utt_model, utt_order, models,
-                        out_stats, stream, true, "srx_estep_stats");
+                        out_stats, stream, true, SRX_STATS_ALL, "srx_estep_stats");
+}
+
+int srx_estep_stats_select(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
+                           int64_t n_utts, int64_t n_frames, const int32_t* utt_model,
+                           const int64_t* utt_order, const srx_models_t* models, int which_stats,
+                           double* out_stats, void* stream) {
+    return estep_common(h, X, dtype, utt_offsets, n_utts, n_frames, utt_model, utt_order, models,
+                        out_stats, stream, true, which_stats, "srx_estep_stats_select");
 }
 
 int srx_estep_stats_generic(srx_handle_t h, const void* X, int dtype, const int64_t* utt_offsets,
@@ -439,7 +482,7 @@ int srx_estep_stats_generic(srx_handle_t h, const void* X, int dtype, const int6
                             const int64_t* utt_order, const srx_models_t* models,
                             double* out_stats, void* stream) {
     return estep_common(h, X, dtype, utt_offsets, n_utts, n_frames, utt_model, utt_order, models,
-                        out_stats, stream, false, "srx_estep_stats_generic");
+                        out_stats, stream, false, SRX_STATS_ALL, "srx_estep_stats_generic");
 }
 
 int srx_mstep(srx_handle_t h, const double* stats, const srx_priors_t* priors, int mode,

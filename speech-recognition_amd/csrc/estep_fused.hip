@@ -516,15 +516,19 @@ __global__ __launch_bounds__(256, 2) void estep_fused_kernel(
                     // the backward recursion needs, b~_t / c_t, is alpha_t over that prediction:
                     // one 16 x 16 mat-vec and four divisions instead of the emission contraction
                     // and its exponentials.  A state the prediction gives no mass has alpha = 0
-                    // and b~ beta = 0 either way.  A prediction below 1e-30 counts as none (the
-                    // hardware reciprocal of a subnormal is infinite, and infinity times a zero
-                    // alpha or a zero of A would be a NaN two instructions later): what such a
-                    // state could add to any posterior of step t - 1 is bounded by that 1e-30.
-                    // beta here is beta_t without its 1 / c_t.
+                    // and b~ beta = 0 either way.  Only a prediction below the smallest normal
+                    // float counts as none (the hardware reciprocal of a subnormal is infinite,
+                    // and infinity times a zero alpha or a zero of A would be a NaN two
+                    // instructions later); the forward pass has no answer for such a step either
+                    // (its own 1 / c_t is that reciprocal).  Everything above goes through: a
+                    // state reached with probability 1e-33 whose emission beats the others by
+                    // more than that carries alpha = 1, and 1 / pred <= 2^126 is finite; since
+                    // alpha beta <= 1 per state, b~ beta <= 1 / pred and its row-stochastic
+                    // combination stay finite too.  beta here is beta_t without its 1 / c_t.
                     const f32x4 pred = matvec(atop, al_prev);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        b[r] = pred[r] > 1e-30f ? al[r] * __builtin_amdgcn_rcpf(pred[r]) : 0.f;
+                        b[r] = pred[r] >= 1.17549435e-38f ? al[r] * __builtin_amdgcn_rcpf(pred[r]) : 0.f;
                     beta = matvec(aop, bb);
                     if (t == T - 1) beta = f32x4{1.f, 1.f, 1.f, 1.f};
                 } else {

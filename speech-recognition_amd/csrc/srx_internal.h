@@ -26,10 +26,9 @@ struct srx_context {
     int exact_f32;   // SRX_OPT_EXACT_F32: keep the float32 paths on exact-f32 matrix instructions
     int estep_path;  // SRX_OPT_ESTEP_PATH
     int viterbi_path;  // SRX_OPT_VITERBI_PATH
-    int estep_stats;   // SRX_OPT_ESTEP_STATS
+    int estep_stats;   // enum srx_estep_stats of the E-step call being queued
     void* ws[WS_NUM];
     size_t ws_bytes[WS_NUM];
-    void* static_scratch;   // this device's copy of the fixed table array (api.hip)
 };
 
 struct srx_mfcc_plan {

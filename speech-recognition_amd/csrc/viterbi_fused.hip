@@ -38,22 +38,17 @@ __device__ __forceinline__ void wave_sync() {
 
 // d of lane 8 v + I (I < 8) of this lane's group of eight, plus la: two DPP adds, each writing
 // one half of every 16-lane row (bank_mask) from that half's own broadcast lane.  A DPP read
-// needs two wait states after a vector write of the same register, and the compiler does not
-// see into the asm: the candidates of a step are formed in order I = 0 .. S - 1 (volatile asm
-// keeps that order) and delta is only rewritten after the last of them, so the s_nop in front
-// of the first one covers them all.
+// needs two wait states after a vector write of the same register, and the hazard recogniser
+// does not look inside inline asm, so every pair brings its own s_nop: whatever the compiler
+// places in front of it (a copy or a split of d or la, the select that rewrites d) has retired
+// by the time the first add reads its operands.
 template <int I>
 __device__ __forceinline__ float bcast_add(float d, float la) {
     float c;
-    if constexpr (I == 0)
-        asm volatile("s_nop 1\n\t"
-                     "v_add_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0x3\n\t"
-                     "v_add_f32_dpp %0, %1, %2 row_newbcast:8 row_mask:0xf bank_mask:0xc"
-                     : "=&v"(c) : "v"(d), "v"(la));
-    else
-        asm volatile("v_add_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0x3\n\t"
-                     "v_add_f32_dpp %0, %1, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xc"
-                     : "=&v"(c) : "v"(d), "v"(la), "n"(I), "n"(I + 8));
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %0, %1, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xc"
+                 : "=&v"(c) : "v"(d), "v"(la), "n"(I), "n"(I + 8));
     return c;
 }
 // value of lane L + N of the row (zero past the row's end)

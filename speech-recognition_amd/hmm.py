@@ -30,7 +30,17 @@ import warnings
 import numpy as np
 
 from . import _lib
-from .runtime import Context, HMMBank, Ragged
+from .runtime import Context, HMMBank, Ragged, column_moments
+
+
+# EM iterations a fit runs launch by launch before it captures one as a graph (short fits
+# never pay for the capture)
+_GRAPH_AFTER = 6
+
+
+def _is_tensor(X):
+    import torch
+    return isinstance(X, torch.Tensor)
 
 
 class ConvergenceMonitor:
@@ -80,7 +90,7 @@ class MyGaussianHMM:
                  startprob_prior=1.0, transmat_prior=1.0, means_prior=0, means_weight=0,
                  covars_prior=1e-2, covars_weight=1, random_state=None, n_iter=10, tol=1e-2,
                  verbose=True, implementation="log", *, mstep="transitions_only", dtype="float64",
-                 device=None):
+                 device=None, use_graph=False):
         if covariance_type != "diag":
             raise ValueError("only covariance_type='diag' is implemented")
         if implementation not in ("log", "scaling"):
@@ -105,6 +115,7 @@ class MyGaussianHMM:
         self.mstep = mstep
         self.dtype = dtype
         self.device = device
+        self.use_graph = use_graph      # replay long fits' iterations as a HIP graph (measured: no gain)
 
     # pickled models carry parameters only, never device state
     def __getstate__(self):
@@ -140,6 +151,8 @@ class MyGaussianHMM:
         (my_hmmlearn/hmm.py:116-134): Dirichlet(1/S) start/transition rows from
         numpy's global generator, then ``np.random.seed(random_state)`` and S
         distinct data rows as means, data variance + min_covar as covariances."""
+        if isinstance(X, Ragged):
+            X = X.X
         self.check_and_set_n_features(X)
         conc = np.full(self.n_components, 1.0 / self.n_components)
         rs = np.random.mtrand._rand
@@ -147,6 +160,14 @@ class MyGaussianHMM:
         self.transmat_ = rs.dirichlet(conc, size=self.n_components)
         np.random.seed(self.random_state)
         rows = np.random.choice(X.shape[0], self.n_components, replace=False)
+        if _is_tensor(X):
+            # features that are already on the device stay there: the chosen rows and the
+            # per-feature variance (the diagonal of np.cov) are all that comes back
+            import torch
+            self.means_ = X[torch.as_tensor(rows, device=X.device)].double().cpu().numpy()
+            self.covars_ = np.tile(column_moments(self._ctx(), X)[1].cpu().numpy() + self.min_covar,
+                                   (self.n_components, 1))
+            return
         self.means_ = np.array(X[rows], dtype=np.float64)
         cv = np.cov(X.T) + self.min_covar * np.eye(X.shape[1])
         if not cv.shape:
@@ -156,8 +177,24 @@ class MyGaussianHMM:
     def _ctx(self):
         return Context.default(self.device)
 
+    def _param_key(self):
+        return hash((self.startprob_.tobytes(), self.transmat_.tobytes(), self.means_.tobytes(),
+                     self._covars_.tobytes(), self.means_.shape))
+
     def _bank(self):
+        """The model's parameters on the device.  Kept between calls for as long as the
+        host arrays hold the values it was made from (their bytes are compared, so assigning
+        or editing an attribute is seen): score / decode on an unchanged model upload nothing."""
         ctx = self._ctx()
+        key = (id(ctx), self.dtype, self._param_key())
+        cached = self.__dict__.get("_dev_bank")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        bank = self._make_bank(ctx)
+        self._dev_bank = (key, bank)
+        return bank
+
+    def _make_bank(self, ctx):
         if self.dtype == "float32":
             # the float32 kernels evaluate the Gaussian exponent in expanded form (see
             # HMMBank.conditioning): fine for normalised features, not for raw ones
@@ -169,7 +206,15 @@ class MyGaussianHMM:
         return HMMBank(ctx, self.startprob_, self.transmat_, self.means_, self._covars_)
 
     def _data(self, X, lengths):
-        X = np.asarray(X)
+        """X: (n_samples, n_features) host array, a device tensor (used where it is), or a
+        ``Ragged`` batch that already carries its lengths."""
+        if isinstance(X, Ragged):
+            self.check_and_set_n_features(X.X)
+            if X.code != (_lib.SRX_F64 if self.dtype == "float64" else _lib.SRX_F32):
+                return Ragged(X.ctx, X.X, dtype=self.dtype, offsets=X.offsets, offsets_host=X.offsets_host)
+            return X
+        if not _is_tensor(X):
+            X = np.asarray(X)
         if X.ndim != 2:
             raise ValueError("X must be 2-D (n_samples, n_features)")
         self.check_and_set_n_features(X)
@@ -183,12 +228,35 @@ class MyGaussianHMM:
     def _pull(self, bank):
         sp, A, mu, cv = bank.params_host()
         self.startprob_, self.transmat_, self.means_, self._covars_ = sp[0], A[0], mu[0], cv[0]
+        # (the bank now holds exactly these values: it stays the model's device copy)
+        self._dev_bank = ((id(bank.ctx), self.dtype, self._param_key()), bank)
 
     # -------------------------------------------------------------- inference
     def compute_log_likelihood(self, X):
         """(T, S) emission log-densities, hmm.py:136-163."""
         data = self._data(X, None)
         return self._bank().emission_loglik(data).cpu().numpy().astype(np.float64)
+
+    def compute_likelihood(self, X):
+        """(T, S) emission densities, hmm.py:144-152: the exponential of the log-densities
+        (the kernels themselves never leave the log domain; far-off frames underflow to 0
+        here exactly as they do in the reference)."""
+        with np.errstate(under="ignore"):
+            return np.exp(self.compute_log_likelihood(X))
+
+    def score_log(self, X, lengths=None, *, compute_posteriors):
+        """hmm.py:257-271.  Same recursion as score_scaling: the reference's log-space
+        forward pass (utils.py:162) adds transmat where it needs its logarithm and is not
+        reproduced."""
+        return self.score_scaling(X, lengths, compute_posteriors=compute_posteriors)
+
+    def fit_scaling(self, X):
+        """(frameprob, log_prob, posteriors, None, None) of one utterance, hmm.py:330-337:
+        the scaled forward / backward lattices are not materialised by the kernels."""
+        lp, post = self.score_scaling(X, None, compute_posteriors=True)
+        return self.compute_likelihood(X), lp, post, None, None
+
+    fit_log = fit_scaling
 
     def score(self, X, lengths=None, *, compute_posteriors=False):
         """Sum over utterances of the forward log-probability, hmm.py:186-196
@@ -260,6 +328,23 @@ class MyGaussianHMM:
         return np.atleast_2d(X), np.array(states, dtype=int)
 
     # --------------------------------------------------------------- training
+    def initialize_sufficient_statistics(self):
+        """The zeroed statistics dict, hmm.py:224-235."""
+        S, D = self.n_components, self.n_features
+        return {"nobs": 0, "start": np.zeros(S), "trans": np.zeros((S, S)), "post": np.zeros(S),
+                "obs": np.zeros((S, D)), "obs**2": np.zeros((S, D))}
+
+    def accumulate_sufficient_statistics(self, stats, X, lattice=None, posteriors=None,
+                                         fwdlattice=None, bwdlattice=None):
+        """Add one utterance's statistics to ``stats`` in place, hmm.py:237-253 and
+        :339-354.  The lattice arguments of the reference's signature are accepted and not
+        used: the E-step kernel computes the utterance's own."""
+        X = np.asarray(X)
+        one, _ = self.do_estep(X, [X.shape[0]])
+        stats["nobs"] += one["nobs"]
+        for k in ("start", "trans", "post", "obs", "obs**2"):
+            stats[k] += one[k]
+
     def do_estep(self, X, lengths):
         """(stats dict, summed log-probability), hmm.py:419-433."""
         data = self._data(X, lengths)
@@ -293,9 +378,11 @@ class MyGaussianHMM:
     def fit(self, X, lengths=None):
         """EM driver, hmm.py:198-222: the log-probability reported for an
         iteration is the one computed before that iteration's M-step."""
-        X = np.asarray(X)
-        if lengths is None:
-            lengths = np.asarray([X.shape[0]])
+        if not isinstance(X, Ragged):
+            if not _is_tensor(X):
+                X = np.asarray(X)
+            if lengths is None:
+                lengths = np.asarray([X.shape[0]])
         self.init(X, lengths)
         return self.fit_from_current(X, lengths)
 
@@ -312,34 +399,73 @@ class MyGaussianHMM:
         # iteration k + 1 runs.  If it says "converged", iteration k + 1 is one too many; its
         # M-step is undone from the snapshot taken just before it, so the parameters and the
         # history are the ones of the reference's loop, which checks after every iteration.
+        # An iteration is a fixed sequence of launches (E-step kernels, the copy of the
+        # log-probability, the snapshot, the M-step kernel); a fit that is still running after
+        # _GRAPH_AFTER iterations captures it once per parity (two pinned slots, two snapshots)
+        # as a HIP graph and replays those: one host call per iteration instead of a dozen.
+        # (use_graph=True.  Off by default: at the reference's own job size the iteration is
+        # bound by the GPU's chain of dependent kernels, 0.106 ms launch by launch and 0.109 ms
+        # replayed, so the host calls were never what it waited for.)
         n_iter = int(self.n_iter)
-        logp = torch.empty((max(n_iter, 1),), dtype=torch.float64).pin_memory()
+        ctx = bank.ctx
+        slots = torch.full((2,), float("nan"), dtype=torch.float64).pin_memory()
         events = [torch.cuda.Event() for _ in range(2)]
-        snap = None
-        stats = None
-        stopped = False
+        # (the events go on the stream that carries the kernels and the copy: the context's
+        # device may not be the process's current one)
+        stream = torch.cuda.current_stream(ctx.device)
+        stats = torch.empty((bank.M, bank.stats_size), dtype=torch.float64, device=ctx.device)
+        snaps = [torch.empty_like(bank._flat) for _ in range(2)]
         # (the reference's own M-step uses the start and transition sums only: the E-step of a
         # small job then skips its pass over the features)
-        bank.ctx.set_estep_stats("transitions" if self.mstep == "transitions_only" else "all")
-        try:
+        which = "transitions" if self.mstep == "transitions_only" else "all"
+
+        def iteration(p):
+            bank.estep(data, out=stats, stats=which)
+            slots[p:p + 1].copy_(stats[0, 1:2], non_blocking=True)
+            snaps[p].copy_(bank._flat)                      # parameters before this M-step
+            bank.mstep(stats, pri, self.mstep)
+
+        def capture(p):
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(ctx.device)
+            side.wait_stream(stream)
+            with torch.cuda.stream(side):
+                g.capture_begin(capture_error_mode="relaxed")
+                try:
+                    iteration(p)
+                finally:
+                    g.capture_end()
+            return g
+
+        graphs = None
+        use_graphs = getattr(self, "use_graph", False) and n_iter > _GRAPH_AFTER + 2
+        stopped = False
+        with torch.cuda.device(ctx.device):
             for k in range(n_iter):
-                stats = bank.estep(data, out=stats)
-                logp[k:k + 1].copy_(stats[0, 1:2], non_blocking=True)
-                snap = bank.snapshot(snap)                      # parameters before M-step k
-                bank.mstep(stats, pri, self.mstep)
-                events[k % 2].record()
+                if use_graphs and graphs is None and k == _GRAPH_AFTER:
+                    try:
+                        graphs = [capture(0), capture(1)]
+                    except Exception as e:      # noqa: BLE001  (no graph: the launches stay eager)
+                        warnings.warn(f"EM iteration not captured as a graph ({e}); running eagerly",
+                                      RuntimeWarning, stacklevel=2)
+                        use_graphs = False
+                if graphs is not None:
+                    graphs[k % 2].replay()
+                else:
+                    iteration(k % 2)
+                events[k % 2].record(stream)
                 if k >= 1:
                     events[(k - 1) % 2].synchronize()
-                    self.monitor_.report(float(logp[k - 1]))
+                    self.monitor_.report(float(slots[(k - 1) % 2]))
                     if self.monitor_.converged:
-                        bank.restore(snap)                      # drop iteration k
+                        bank.restore(snaps[k % 2])              # drop iteration k
                         stopped = True
                         break
-        finally:
-            bank.ctx.set_estep_stats("all")
-        if not stopped and n_iter >= 1:
-            events[(n_iter - 1) % 2].synchronize()
-            self.monitor_.report(float(logp[n_iter - 1]))
+            if not stopped and n_iter >= 1:
+                events[(n_iter - 1) % 2].synchronize()
+                self.monitor_.report(float(slots[(n_iter - 1) % 2]))
+            torch.cuda.current_stream(ctx.device).synchronize()
+        del graphs
         self._pull(bank)
         if (self.transmat_.sum(axis=1) == 0).any():
             print("Some rows of transmat_ have zero sum because no transition from the state "
@@ -380,6 +506,10 @@ class GaussianHMM(MyGaussianHMM):
 
     def init(self, X, lengths=None):
         from sklearn.cluster import KMeans
+        if isinstance(X, Ragged):
+            X = X.X
+        if _is_tensor(X):          # (the clustering runs on the host, once per fit)
+            X = X.double().cpu().numpy()
         X = np.asarray(X, dtype=np.float64)
         self.check_and_set_n_features(X)
         S = self.n_components

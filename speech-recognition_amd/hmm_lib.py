@@ -16,8 +16,9 @@ import numpy as np
 from scipy.io import wavfile
 
 from . import mfcc as fe
+from . import recognizer as _rec
 from .hmm import GaussianHMM
-from .recognizer import WORDS, _word_of, extract_mfcc_calc, score_matrix   # noqa: F401
+from .recognizer import WORDS, _word_of, classify, extract_mfcc_calc, score_matrix, word_files   # noqa: F401
 
 
 def _load(audio_path, sample_rate):
@@ -36,10 +37,16 @@ def _load(audio_path, sample_rate):
     return y.mean(axis=1) if y.ndim == 2 else y
 
 
-def extract_many(audio_paths, sample_rate, n_mfcc=13, dtype="float32"):
-    """extract_mfcc of many files in one launch -> (packed features, lengths)."""
+def features_of(audio_paths, sample_rate, n_mfcc=13, dtype="float32"):
+    """extract_mfcc of many files in one launch, left on the device (a ``Ragged`` batch)."""
     sigs = [_load(p, sample_rate) for p in audio_paths]
-    return fe.librosa_mfcc_batch(sigs, sample_rate, n_mfcc, zscore=True, dtype=dtype)
+    return fe.librosa_mfcc_ragged(sigs, sample_rate, n_mfcc, zscore=True, dtype=dtype)
+
+
+def extract_many(audio_paths, sample_rate, n_mfcc=13, dtype="float32", to_host=True):
+    """extract_mfcc of many files in one launch -> (packed features, lengths)."""
+    data = features_of(audio_paths, sample_rate, n_mfcc, dtype=dtype)
+    return (data.X.cpu().numpy() if to_host else data.X), np.diff(data.offsets_host)
 
 
 def extract_mfcc(audio_path, sample_rate, n_mfcc=13):
@@ -51,31 +58,24 @@ def extract_mfcc(audio_path, sample_rate, n_mfcc=13):
 def train_hmm(models, model_name, audio_files, labels, sample_rate, i=0, *, model_dir="SavedModels",
               n_components=3, tol=1e-4, n_iter=2000, save=True, verbose=True, **hmm_kw):
     """One GaussianHMM per distinct label stored in ``models[label]`` and pickled as
-    ``<label><model_name>``, HMM_lib.py:26-42."""
+    ``<label><model_name>``, HMM_lib.py:26-42.  The features of all files come from one
+    front-end launch and stay on the device for the fits (the models compute in float64, the
+    class default, on the float32 features widened there)."""
     print("Training started ...")
-    labels = np.asarray(labels)
-    feats, lengths = extract_many(audio_files, sample_rate)
-    off = np.concatenate([[0], np.cumsum(lengths)])
-    for label in np.unique(labels):
-        idx = [k for k in range(len(labels)) if labels[k] == label]
-        X = np.vstack([feats[off[k]:off[k + 1]] for k in idx]).astype(np.float64)
-        model = GaussianHMM(n_components=n_components, tol=tol, n_iter=n_iter,
-                            implementation="log", verbose=verbose, **hmm_kw)
-        model.fit(X, [int(lengths[k]) for k in idx])
-        models[label] = model
-        if save:
-            os.makedirs(model_dir, exist_ok=True)
-            path = os.path.join(model_dir, f"{label}{model_name}")
-            with open(path, "wb") as f:
-                pickle.dump(model, f)
-            print(f"Model for {label} saved at {path}")
+    data = features_of(audio_files, sample_rate)
+    _rec._fit_per_label(GaussianHMM, data, labels, lambda label: f"{label}{model_name}", models,
+                        model_dir, save,
+                        dict(n_components=n_components, tol=tol, n_iter=n_iter, implementation="log",
+                             verbose=verbose, **hmm_kw))
 
 
 def recognize_many(models, audio_paths, sample_rate):
-    feats, lengths = extract_many(audio_paths, sample_rate)
-    scores = score_matrix(models, feats, lengths, dtype="float32")
+    """(labels, scores) of many files on the librosa-convention features: front-end,
+    scoring and arg-max on the device, only labels and scores come back."""
+    data = features_of(audio_paths, sample_rate)
+    labels, scores = classify(models, data)
     names = list(models.keys())
-    return [names[int(np.argmax(row))] for row in scores], scores
+    return [names[int(k)] for k in labels.cpu().numpy()], scores.cpu().numpy()
 
 
 def recognize_lib(models, audio_path, sample_rate):
@@ -85,8 +85,7 @@ def recognize_lib(models, audio_path, sample_rate):
 
 def recognize(models, audio_path, sample_rate):
     """HMM_lib.py:45-48: the same models on the reference's own front-end."""
-    from .recognizer import recognize as _recognize
-    return _recognize(models, audio_path, sample_rate)
+    return _rec.recognize(models, audio_path, sample_rate)
 
 
 def load_models(model_name, model_dir="models"):
@@ -106,32 +105,15 @@ def load_models(model_name, model_dir="models"):
 def train_using_all_files(models, model_name, directory="cleaned_audios_3005", sample_rate=22050,
                           n_files=25, **kw):
     """HMM_lib.py:55-65 with the module-level ``models`` made an argument."""
-    audio_files, labels = [], []
-    for word in WORDS:
-        for k in range(n_files):
-            audio_files.append(f"{directory}/{word}_{k + 1}.wav")
-            labels.append(word)
+    audio_files, labels = word_files(directory, n_files)
     train_hmm(models, model_name, audio_files, labels, sample_rate, **kw)
 
 
 def test_trained_model(models, directory, sample_rate, folds_dir="Folds", lists=None):
-    """HMM_lib.py:130-161 (recognize_lib on every validation sample)."""
-    lists = lists or ["validation 1.txt", "validation 1.txt", "validation 2.txt",
-                      "validation 3.txt", "validation 4.txt", "validation 5.txt"]
-    results = []
-    for name in lists:
-        with open(os.path.join(folds_dir, name)) as f:
-            samples = [l.strip() for l in f if l.strip()]
-        print(name)
-        pred, _ = recognize_many(models, [f"{directory}/{s}" for s in samples], sample_rate)
-        right = 0
-        for s, p in zip(samples, pred):
-            print(_word_of(s))
-            print(p)
-            right += int(p == _word_of(s))
-        print(f"right: {right}; wrong: {len(samples) - right}")
-        results.append((right, len(samples) - right))
-    return results
+    """HMM_lib.py:130-161 (recognize_lib on every validation sample): the loop and the
+    printed lines of the other harness with this module's recogniser."""
+    return _rec.test_trained_model(models, directory, sample_rate, folds_dir=folds_dir, lists=lists,
+                                   recognizer=recognize_many)
 
 
 test_trained_model.__test__ = False   # not a pytest test

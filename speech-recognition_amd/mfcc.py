@@ -33,25 +33,42 @@ def mel_filterbank(NFFT, sample_rate=16000, num_filters=26):
     return filterbank_host(NFFT, sample_rate, num_filters)
 
 
+def _pack(signals, dtype):
+    lens = np.array([len(s) for s in signals], dtype=np.int64)
+    so = np.zeros(len(signals) + 1, dtype=np.int64)
+    np.cumsum(lens, out=so[1:])
+    npdt = np.float64 if dtype == "float64" else np.float32
+    if len(signals) == 1:
+        packed = np.ascontiguousarray(signals[0], dtype=npdt).reshape(-1)
+    else:
+        packed = np.concatenate([np.asarray(s, dtype=npdt).reshape(-1) for s in signals]) \
+            if len(signals) else np.zeros(0, dtype=npdt)
+    return packed, so
+
+
+def extract_ragged(signals, sample_rate, *, nfft=1024, n_mel=26, mel_sample_rate=16000, n_ceps=13,
+                   delta_order=1, zscore=True, dtype="float32", ctx=None):
+    """MFCC(+delta) features of many utterances in one launch, left on the device: a
+    ``Ragged`` batch (packed (sum T_u, n_feat) features + frame offsets) that scoring,
+    decoding and training take as it is."""
+    ctx = ctx or Context.default()
+    plan = _plan(ctx, sample_rate, nfft=nfft, n_mel=n_mel, mel_sample_rate=mel_sample_rate,
+                 n_ceps=n_ceps, delta_order=delta_order, zscore=zscore)
+    packed, so = _pack(signals, dtype)
+    return plan.run_ragged(packed, so, dtype=dtype)
+
+
 def extract_batch(signals, sample_rate, *, nfft=1024, n_mel=26, mel_sample_rate=16000, n_ceps=13,
                   delta_order=1, zscore=True, dtype="float32", ctx=None, to_host=True):
     """MFCC(+delta) features of many utterances in one launch.
 
     signals: list of 1-D arrays.  Returns (features, lengths): features is the
-    packed (sum T_u, n_feat) matrix, lengths the frames per utterance."""
-    ctx = ctx or Context.default()
-    plan = _plan(ctx, sample_rate, nfft=nfft, n_mel=n_mel, mel_sample_rate=mel_sample_rate,
-                 n_ceps=n_ceps, delta_order=delta_order, zscore=zscore)
-    lens = np.array([len(s) for s in signals], dtype=np.int64)
-    so = np.zeros(len(signals) + 1, dtype=np.int64)
-    np.cumsum(lens, out=so[1:])
-    npdt = np.float64 if dtype == "float64" else np.float32
-    packed = np.concatenate([np.asarray(s, dtype=npdt).reshape(-1) for s in signals]) \
-        if len(signals) else np.zeros(0, dtype=npdt)
-    feats, fo = plan.run(packed, so, dtype=dtype)
-    if to_host:
-        feats = feats.cpu().numpy()
-    return feats, np.diff(fo)
+    packed (sum T_u, n_feat) matrix (a numpy array, or the device tensor with
+    to_host=False), lengths the frames per utterance."""
+    data = extract_ragged(signals, sample_rate, nfft=nfft, n_mel=n_mel, mel_sample_rate=mel_sample_rate,
+                          n_ceps=n_ceps, delta_order=delta_order, zscore=zscore, dtype=dtype, ctx=ctx)
+    feats = data.X.cpu().numpy() if to_host else data.X
+    return feats, np.diff(data.offsets_host)
 
 
 def compute_mfcc(signal, sample_rate, dtype="float64"):
@@ -77,6 +94,16 @@ def extract_features(signal, sample_rate, dtype="float64"):
     return f.astype(np.float64)
 
 
+def librosa_mfcc_ragged(signals, sample_rate, n_mfcc=13, *, zscore=False, dtype="float32", ctx=None, **kw):
+    """``librosa_mfcc_batch`` with the features left on the device as a ``Ragged`` batch."""
+    ctx = ctx or Context.default()
+    key = ("librosa", id(ctx), int(sample_rate), int(n_mfcc), bool(zscore)) + tuple(sorted(kw.items()))
+    if key not in _plans:
+        _plans[key] = MfccPlan.librosa(ctx, sample_rate, n_mfcc=n_mfcc, zscore=zscore, **kw)
+    packed, so = _pack(signals, dtype)
+    return _plans[key].run_ragged(packed, so, dtype=dtype)
+
+
 def librosa_mfcc_batch(signals, sample_rate, n_mfcc=13, *, zscore=False, dtype="float32", ctx=None,
                        to_host=True, **kw):
     """``librosa.feature.mfcc(y=, sr=, n_mfcc=)`` conventions (the front-end of
@@ -84,17 +111,6 @@ def librosa_mfcc_batch(signals, sample_rate, n_mfcc=13, *, zscore=False, dtype="
     arguments as ``MfccPlan.librosa``.  Returns (packed (sum T, n_mfcc), lengths).
     librosa itself is not used (it is a third-party package the reference does not
     pin); this follows the published algorithm of its 0.10 line."""
-    ctx = ctx or Context.default()
-    key = ("librosa", id(ctx), int(sample_rate), int(n_mfcc), bool(zscore)) + tuple(sorted(kw.items()))
-    if key not in _plans:
-        _plans[key] = MfccPlan.librosa(ctx, sample_rate, n_mfcc=n_mfcc, zscore=zscore, **kw)
-    lens = np.array([len(s) for s in signals], dtype=np.int64)
-    so = np.zeros(len(signals) + 1, dtype=np.int64)
-    np.cumsum(lens, out=so[1:])
-    npdt = np.float64 if dtype == "float64" else np.float32
-    packed = np.concatenate([np.asarray(s, dtype=npdt).reshape(-1) for s in signals]) \
-        if len(signals) else np.zeros(0, dtype=npdt)
-    feats, fo = _plans[key].run(packed, so, dtype=dtype)
-    if to_host:
-        feats = feats.cpu().numpy()
-    return feats, np.diff(fo)
+    data = librosa_mfcc_ragged(signals, sample_rate, n_mfcc, zscore=zscore, dtype=dtype, ctx=ctx, **kw)
+    feats = data.X.cpu().numpy() if to_host else data.X
+    return feats, np.diff(data.offsets_host)

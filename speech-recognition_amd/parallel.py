@@ -97,12 +97,8 @@ class BaumWelchTrainer:
         """One EM iteration; returns the per-model log-probabilities (device
         tensor, computed with the parameters before the update)."""
         # (a transitions-only M-step reads no sum over the features: small jobs skip that pass)
-        ctx = self.bank.ctx
-        ctx.set_estep_stats("transitions" if self.mode == "transitions_only" else "all")
-        try:
-            self.bank.estep(self.data, self.utt_model, self.utt_order, out=self.stats)
-        finally:
-            ctx.set_estep_stats("all")
+        self.bank.estep(self.data, self.utt_model, self.utt_order, out=self.stats,
+                        stats="transitions" if self.mode == "transitions_only" else "all")
         allreduce_stats(self.stats)
         logprob = self.stats[:, 1].clone()
         self.bank.mstep(self.stats, self.priors, self.mode)

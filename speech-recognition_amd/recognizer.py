@@ -14,7 +14,7 @@ import numpy as np
 from . import SpeechUtil as su
 from . import mfcc as fe
 from .hmm import MyGaussianHMM
-from .runtime import Context, HMMBank, Ragged
+from .runtime import Context, HMMBank, Ragged, argmax_scores
 
 WORDS = ["play_music", "stop_music", "turn_off_the_lights", "turn_on_the_lights",
          "what_time_is_it", "odessa"]          # HMM_final.py:64
@@ -26,10 +26,46 @@ def extract_mfcc_calc(audio_path, sample_rate, n_mfcc=13, dtype="float64"):
     return fe.extract_features(signal, sample_rate, dtype=dtype)
 
 
-def extract_many(audio_paths, sample_rate, dtype="float64"):
-    """Features of many files in one launch -> (packed features, lengths)."""
+def features_of(audio_paths, sample_rate, dtype="float64"):
+    """Features of many files in one launch, left on the device: a ``Ragged`` batch."""
     sigs = [su.read_recording(str(p).replace(".wav", ""), sample_rate) for p in audio_paths]
-    return fe.extract_batch(sigs, sample_rate, dtype=dtype)
+    return fe.extract_ragged(sigs, sample_rate, dtype=dtype)
+
+
+def extract_many(audio_paths, sample_rate, dtype="float64", to_host=True):
+    """Features of many files in one launch -> (packed features, lengths); the features as
+    a numpy array, or with to_host=False as the device tensor the kernels wrote."""
+    data = features_of(audio_paths, sample_rate, dtype=dtype)
+    return (data.X.cpu().numpy() if to_host else data.X), np.diff(data.offsets_host)
+
+
+def _gather_utterances(data, idx):
+    """The utterances ``idx`` of a device batch as one packed device tensor + their lengths
+    (device-to-device copies; the features never visit the host)."""
+    import torch
+    off = data.offsets_host
+    parts = [data.X[int(off[k]):int(off[k + 1])] for k in idx]
+    X = torch.cat(parts) if len(parts) != 1 else parts[0]
+    return X, [int(off[k + 1] - off[k]) for k in idx]
+
+
+def _fit_per_label(model_cls, data, labels, make_name, models, model_dir, save, ctor_kw):
+    """The label loop shared by the two harnesses' train_hmm (HMM_final.py:28-46,
+    HMM_lib.py:28-42): a model per distinct label, fitted on that label's utterances (taken
+    from the device batch), stored in ``models`` and pickled."""
+    labels = np.asarray(labels)
+    for label in np.unique(labels):
+        idx = [k for k in range(len(labels)) if labels[k] == label]
+        X, L = _gather_utterances(data, idx)
+        model = model_cls(**ctor_kw)
+        model.fit(X, L)
+        models[label] = model
+        if save:
+            os.makedirs(model_dir, exist_ok=True)
+            path = os.path.join(model_dir, make_name(label))
+            with open(path, "wb") as f:
+                pickle.dump(model, f)
+            print(f"Model for {label} saved at {path}")
 
 
 def train_hmm(models, audio_files, labels, sample_rate, i=-1, *, model_dir="SavedModels",
@@ -39,47 +75,79 @@ def train_hmm(models, audio_files, labels, sample_rate, i=-1, *, model_dir="Save
     models are ``MyGaussianHMM(n_components=3, tol=1e-4, n_iter=2000,
     implementation="scaling")`` and ``fit`` re-estimates start and transition
     probabilities only; ``mstep="full"`` (and any other constructor argument, e.g.
-    ``random_state``, ``dtype``) goes through ``hmm_kw``."""
+    ``random_state``, ``dtype``) goes through ``hmm_kw``.  The features of all files come
+    from one front-end launch and stay on the device for the fits."""
     print("Training started ...")
-    labels = np.asarray(labels)
-    feats, lengths = extract_many(audio_files, sample_rate, dtype=hmm_kw.get("dtype", "float64"))
-    off = np.concatenate([[0], np.cumsum(lengths)])
-    for label in np.unique(labels):
-        idx = [k for k in range(len(labels)) if labels[k] == label]
-        X = np.vstack([feats[off[k]:off[k + 1]] for k in idx])
-        L = [int(lengths[k]) for k in idx]
-        model = MyGaussianHMM(n_components=n_components, tol=tol, n_iter=n_iter,
-                              implementation="scaling", verbose=verbose, **hmm_kw)
-        model.fit(X, L)
-        models[label] = model
-        if save:
-            os.makedirs(model_dir, exist_ok=True)
-            name = f"{label}_hmm_model.pkl" if i == -1 else f"{label}_{i}_hmm_model.pkl"
-            path = os.path.join(model_dir, name)
-            with open(path, "wb") as f:
-                pickle.dump(model, f)
-            print(f"Model for {label} saved at {path}")
+    data = features_of(audio_files, sample_rate, dtype=hmm_kw.get("dtype", "float64"))
+    _fit_per_label(MyGaussianHMM, data, labels,
+                   lambda label: f"{label}_hmm_model.pkl" if i == -1 else f"{label}_{i}_hmm_model.pkl",
+                   models, model_dir, save,
+                   dict(n_components=n_components, tol=tol, n_iter=n_iter, implementation="scaling",
+                        verbose=verbose, **hmm_kw))
 
 
-def score_matrix(models, feats, lengths, dtype="float64", ctx=None):
+_banks = {}          # (context, parameter bytes of the models) -> HMMBank; a handful of entries
+
+
+def bank_of(models, ctx=None):
+    """The word models of a dict as one device bank, in insertion order.  Cached on the
+    models' parameter values, so that recognising file after file with the same models
+    uploads them once."""
+    ctx = ctx or Context.default()
+    ms = list(models.values()) if isinstance(models, dict) else list(models)
+    key = (id(ctx),) + tuple(m._param_key() for m in ms)
+    bank = _banks.get(key)
+    if bank is None:
+        if len(_banks) >= 8:
+            _banks.pop(next(iter(_banks)))
+        bank = _banks[key] = HMMBank.from_models(ctx, ms)
+    return bank
+
+
+def score_matrix(models, feats, lengths=None, dtype="float64", ctx=None, to_host=True):
     """(U, n_models) log-likelihoods in ``models`` insertion order: the dict
-    comprehension of HMM_final.py:51 for every utterance at once."""
+    comprehension of HMM_final.py:51 for every utterance at once.  feats: packed features
+    (host array or device tensor) with ``lengths``, or a ``Ragged`` batch."""
     ctx = ctx or Context.default()
     ms = list(models.values())
     shapes = {(m.n_components, m.means_.shape[1]) for m in ms}
-    data = Ragged(ctx, feats, lengths, dtype=dtype)
+    data = feats if isinstance(feats, Ragged) else Ragged(ctx, feats, lengths, dtype=dtype)
     if len(shapes) == 1:
-        return HMMBank.from_models(ctx, ms).score(data).cpu().numpy()
-    cols = [HMMBank.from_models(ctx, [m]).score(data).cpu().numpy()[:, 0] for m in ms]
-    return np.stack(cols, axis=1)
+        scores = bank_of(models, ctx).score(data)
+    else:
+        import torch
+        scores = torch.stack([bank_of([m], ctx).score(data)[:, 0] for m in ms], dim=1).contiguous()
+    return scores.cpu().numpy() if to_host else scores
+
+
+def classify(models, data, ctx=None):
+    """(labels (U,) int32, scores (U, n_models) float64) on the device for a ``Ragged``
+    batch: scores against every model, then max(scores, key=scores.get) of
+    HMM_final.py:52 as an arg-max kernel (first best model in insertion order)."""
+    ctx = ctx or data.ctx
+    scores = score_matrix(models, data, ctx=ctx, to_host=False)
+    return argmax_scores(ctx, scores), scores
+
+
+def recognize_device(models, audio, sample_offsets, sample_rate, dtype="float32", ctx=None, **front_end):
+    """Audio that is already on the device -> (labels, scores, features), all on the device:
+    front-end, scoring against every model and the arg-max as one chain of launches with no
+    host copy in between.  audio: packed 1-D device tensor, sample_offsets: host int64
+    [U+1]; front_end: keyword arguments of ``MfccPlan`` (default: the reference's mfcc.py)."""
+    ctx = ctx or Context.default()
+    plan = fe._plan(ctx, sample_rate, **front_end)
+    data = plan.run_ragged(audio, sample_offsets, dtype=dtype)
+    labels, scores = classify(models, data, ctx)
+    return labels, scores, data
 
 
 def recognize_many(models, audio_paths, sample_rate, dtype="float64"):
-    feats, lengths = extract_many(audio_paths, sample_rate, dtype=dtype)
-    scores = score_matrix(models, feats, lengths, dtype=dtype)
+    """(labels, (U, n_models) scores) of many files: one front-end launch, one scoring
+    launch, one arg-max launch; only the labels and the score matrix come back."""
+    data = features_of(audio_paths, sample_rate, dtype=dtype)
+    labels, scores = classify(models, data)
     names = list(models.keys())
-    # max(scores, key=scores.get): the first best key in insertion order
-    return [names[int(np.argmax(row))] for row in scores], scores
+    return [names[int(k)] for k in labels.cpu().numpy()], scores.cpu().numpy()
 
 
 def recognize(models, audio_path, sample_rate, dtype="float64"):
@@ -105,11 +173,7 @@ def load_models(model_dir="models"):
 def train_using_all_files(models, directory="cleaned_audios_3005", sample_rate=22050, n_files=25,
                           **kw):
     """HMM_final.py:59-69 with the module-level ``models`` made an argument."""
-    audio_files, labels = [], []
-    for word in WORDS:
-        for k in range(n_files):
-            audio_files.append(f"{directory}/{word}_{k + 1}.wav")
-            labels.append(word)
+    audio_files, labels = word_files(directory, n_files)
     train_hmm(models, audio_files, labels, sample_rate, **kw)
 
 
@@ -118,11 +182,25 @@ def _word_of(sample):
     return stem[: stem.rfind("_")]
 
 
+def word_files(directory, n_files=25):
+    """(files, labels) of the training set both harnesses use, HMM_final.py:59-69."""
+    audio_files, labels = [], []
+    for word in WORDS:
+        for k in range(n_files):
+            audio_files.append(f"{directory}/{word}_{k + 1}.wav")
+            labels.append(word)
+    return audio_files, labels
+
+
 def test_trained_model(models, directory, sample_rate, folds_dir="Folds", lists=None,
-                       dtype="float64"):
+                       dtype="float64", recognizer=None):
     """Score the validation lists and print right / wrong per list,
     HMM_final.py:134-165 (fold 1 is listed twice there).  Returns the
-    (right, wrong) pairs."""
+    (right, wrong) pairs.  recognizer(models, paths, sample_rate) -> (labels, scores):
+    default ``recognize_many`` with ``dtype``."""
+    if recognizer is None:
+        def recognizer(models, paths, sample_rate):
+            return recognize_many(models, paths, sample_rate, dtype=dtype)
     lists = lists or ["validation 1.txt", "validation 1.txt", "validation 2.txt",
                       "validation 3.txt", "validation 4.txt", "validation 5.txt"]
     results = []
@@ -130,8 +208,7 @@ def test_trained_model(models, directory, sample_rate, folds_dir="Folds", lists=
         with open(os.path.join(folds_dir, name)) as f:
             samples = [l.strip() for l in f if l.strip()]
         print(name)
-        pred, _ = recognize_many(models, [f"{directory}/{s}" for s in samples], sample_rate,
-                                 dtype=dtype)
+        pred, _ = recognizer(models, [f"{directory}/{s}" for s in samples], sample_rate)
         right = 0
         for s, p in zip(samples, pred):
             print(_word_of(s))

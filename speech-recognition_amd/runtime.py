@@ -76,14 +76,6 @@ class Context:
         code = {"auto": _lib.SRX_ESTEP_AUTO, "fused": _lib.SRX_ESTEP_FUSED, "lane": _lib.SRX_ESTEP_LANE}[path]
         check(lib.srx_set_option(self._h, _lib.SRX_OPT_ESTEP_PATH, code), "srx_set_option")
 
-    def set_estep_stats(self, which):
-        """What the caller of the E-step will use: "all" statistics or "transitions" (count,
-        log-probability, start and transition sums: what the reference's own fit()
-        re-estimates from, my_hmmlearn/hmm.py:237-253).  With "transitions" the sums over the
-        features come back zero: the kernels leave out their pass over X."""
-        code = {"all": _lib.SRX_STATS_ALL, "transitions": _lib.SRX_STATS_TRANSITIONS}[which]
-        check(lib.srx_set_option(self._h, _lib.SRX_OPT_ESTEP_STATS, code), "srx_set_option")
-
     def set_viterbi_path(self, path):
         """Kernels of float32 Viterbi decoding for models of at most 8 states: "auto" / "fused"
         (one kernel, log-densities kept on the chip) or "split" (an emission kernel, then a
@@ -139,7 +131,10 @@ def offsets_from_lengths(lengths, total=None):
 class Ragged:
     """Packed frames [n_frames, D] on the device plus utterance offsets."""
 
-    def __init__(self, ctx, X, lengths=None, dtype="float32", offsets=None):
+    def __init__(self, ctx, X, lengths=None, dtype="float32", offsets=None, offsets_host=None):
+        """X: host array or device tensor (a device tensor of the right dtype is taken as it
+        is, no copy).  lengths: frames per utterance (host); or offsets: int64 device tensor
+        [U+1], with offsets_host its host copy if the caller has one."""
         tdt, self.code, _ = dtype_info(dtype)
         self.ctx = ctx
         if isinstance(X, torch.Tensor):
@@ -153,7 +148,7 @@ class Ragged:
             self.X = ctx.tensor(X, tdt)
         self.n_frames, self.D = int(self.X.shape[0]), int(self.X.shape[1])
         if offsets is not None:
-            self.offsets_host = None
+            self.offsets_host = None if offsets_host is None else np.asarray(offsets_host, dtype=np.int64)
             self.offsets = offsets.to(ctx.device, torch.int64).contiguous()
             self.U = int(self.offsets.numel()) - 1
         else:
@@ -183,6 +178,33 @@ class Ragged:
                 order = self.ctx.tensor(np.argsort(-bucket, kind="stable").astype(np.int64))
             self._length_order = order
         return self._length_order
+
+
+def argmax_scores(ctx, scores, out=None):
+    """max(scores, key=scores.get) of recognize (HMM_final.py:51-52) for every row of a
+    (U, M) float64 score matrix on the device: int32 index of the first best column."""
+    if scores.dim() != 2 or scores.dtype != torch.float64 or not scores.is_contiguous():
+        raise ValueError("scores must be a contiguous (U, M) float64 device tensor")
+    U, M = int(scores.shape[0]), int(scores.shape[1])
+    if out is None:
+        out = torch.empty((U,), dtype=torch.int32, device=ctx.device)
+    check(lib.srx_argmax_scores(ctx.handle, ptr(scores), U, M, ptr(out), ctx.stream_ptr()),
+          "srx_argmax_scores")
+    return out
+
+
+def column_moments(ctx, X):
+    """(mean, variance with ddof = 1) of every column of a (n, D) device tensor, float64
+    device tensors: the diagonal of np.cov(X.T) that MyGaussianHMM.init uses
+    (my_hmmlearn/hmm.py:131-132)."""
+    code = {torch.float32: _lib.SRX_F32, torch.float64: _lib.SRX_F64}[X.dtype]
+    X = X.contiguous()
+    n, D = int(X.shape[0]), int(X.shape[1])
+    mean = torch.empty((D,), dtype=torch.float64, device=ctx.device)
+    var = torch.empty((D,), dtype=torch.float64, device=ctx.device)
+    check(lib.srx_column_moments(ctx.handle, ptr(X), code, n, D, ptr(mean), ptr(var), ctx.stream_ptr()),
+          "srx_column_moments")
+    return mean, var
 
 
 class HMMBank:
@@ -284,6 +306,13 @@ class HMMBank:
                  C.byref(self._struct), ptr(out), self.ctx.stream_ptr()), "srx_forward_score")
         return out
 
+    def classify(self, data, scores=None, labels=None):
+        """(labels (U,) int32, scores (U, M) float64), both on the device: every utterance
+        scored against all models and given the index of its first best one -- recognize
+        (HMM_final.py:49-52) for a batch, nothing leaves the GPU."""
+        scores = self.score(data, out=scores)
+        return argmax_scores(self.ctx, scores, out=labels), scores
+
     def score_static(self, data, out):
         """``score`` through srx_forward_score_static: float32 only, no device memory is
         allocated (``out`` must be the caller's (U, M) float64 tensor)."""
@@ -325,17 +354,29 @@ class HMMBank:
                                  self.ctx.stream_ptr()), "srx_posteriors")
         return lp, gamma
 
-    def estep(self, data, utt_model=None, utt_order=None, out=None, generic=False):
-        """Packed statistics (M, stats_size) float64 on the device."""
+    def estep(self, data, utt_model=None, utt_order=None, out=None, generic=False, stats="all"):
+        """Packed statistics (M, stats_size) float64 on the device.  stats: what the caller
+        will use of them -- "all", or "transitions" (count, log-probability, start and
+        transition sums: what the reference's own fit() re-estimates from,
+        my_hmmlearn/hmm.py:435-451); with "transitions" the sums over the features come back
+        zero, the kernels leave out their pass over X."""
         self._check(data)
         if out is None:
             out = torch.empty((self.M, self.stats_size), dtype=torch.float64, device=self.ctx.device)
-        fn = lib.srx_estep_stats_generic if generic else lib.srx_estep_stats
+        which = {"all": _lib.SRX_STATS_ALL, "transitions": _lib.SRX_STATS_TRANSITIONS}[stats]
         utt_model = self._utt_model(data, utt_model)
-        check(fn(self.ctx.handle, ptr(data.X), data.code, ptr(data.offsets), data.U,
-                                  data.n_frames, ptr(utt_model), ptr(utt_order),
-                                  C.byref(self._struct), ptr(out), self.ctx.stream_ptr()),
-              "srx_estep_stats")
+        if generic:
+            if which != _lib.SRX_STATS_ALL:
+                raise ValueError("the shape-generic E-step computes all statistics")
+            check(lib.srx_estep_stats_generic(self.ctx.handle, ptr(data.X), data.code, ptr(data.offsets),
+                                              data.U, data.n_frames, ptr(utt_model), ptr(utt_order),
+                                              C.byref(self._struct), ptr(out), self.ctx.stream_ptr()),
+                  "srx_estep_stats_generic")
+        else:
+            check(lib.srx_estep_stats_select(self.ctx.handle, ptr(data.X), data.code, ptr(data.offsets),
+                                             data.U, data.n_frames, ptr(utt_model), ptr(utt_order),
+                                             C.byref(self._struct), which, ptr(out),
+                                             self.ctx.stream_ptr()), "srx_estep_stats")
         return out
 
     def mstep(self, stats, priors=None, mode="full"):
@@ -505,7 +546,10 @@ class MfccPlan:
                 slices.append((u0, u1, self.ctx.tensor(so[u0:u1 + 1] - so[u0]),
                                self.ctx.tensor(fo[u0:u1 + 1] - fo[u0])))
             u0 = u1
-        return {"so": so, "fo": fo, "slices": slices}
+        # (one slice that starts at zero: its frame offsets are the batch's)
+        fo_dev = slices[0][3] if len(slices) == 1 and slices[0][0] == 0 and slices[0][1] == len(lens) \
+            else self.ctx.tensor(fo)
+        return {"so": so, "fo": fo, "slices": slices, "fo_dev": fo_dev}
 
     def run(self, audio, sample_offsets_host, dtype="float32", out=None):
         """audio: packed 1-D device tensor (or host array); returns
@@ -528,6 +572,12 @@ class MfccPlan:
                   "srx_mfcc_batch")
         self._keep = a          # the samples must outlive the asynchronous kernels
         return out, fo
+
+    def run_ragged(self, audio, sample_offsets_host, dtype="float32", out=None):
+        """``run`` with the result as a ``Ragged`` batch on the device (features and frame
+        offsets stay where the kernels wrote them): what scoring, decoding and the E-step take."""
+        feats, fo = self.run(audio, sample_offsets_host, dtype=dtype, out=out)
+        return Ragged(self.ctx, feats, dtype=dtype, offsets=self._prepared["fo_dev"], offsets_host=fo)
 
     def close(self):
         if self._p:

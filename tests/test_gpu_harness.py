@@ -186,3 +186,72 @@ def test_train_hmm_float32_history(sra, hg, site):
         ref = hg[f"train_{w}_hist"][:len(h)]
         assert len(h) == min(5, int(hg[f"train_{w}_iter"]))
         np.testing.assert_allclose(h, ref, rtol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_device_resident_chain_equals_the_two_step_path(sra, hg, site, dtype):
+    """recognize_many keeps the features on the device from the front-end kernels to the
+    arg-max kernel.  The same files taken the long way round -- features to the host, back
+    into a batch, scores to the host, numpy's arg-max -- give the same scores and labels bit
+    for bit; so does the chain started from audio that is already on the device."""
+    import torch
+    sr = int(hg["sr"])
+    rec = sra.recognizer
+    models = _fold1_models(sra, dtype)
+    names = list(models)
+    paths = [str(site / "wav" / f"{n}.wav") for n in hg["names"]]
+    pred, scores = rec.recognize_many(models, paths, sr, dtype=dtype)
+    # the long way round
+    feats, lengths = rec.extract_many(paths, sr, dtype=dtype)
+    assert isinstance(feats, np.ndarray)
+    scores2 = rec.score_matrix(models, feats, lengths, dtype=dtype)
+    assert np.array_equal(scores, scores2)
+    assert pred == [names[int(np.argmax(r))] for r in scores2]
+    # features left on the device are the tensor the kernels wrote, and a batch made of it
+    # holds that very memory
+    data = rec.features_of(paths, sr, dtype=dtype)
+    assert data.X.is_cuda and np.array_equal(data.X.cpu().numpy(), feats)
+    ctx = sra.Context.default()
+    again = sra.Ragged(ctx, data.X, lengths, dtype=dtype)
+    assert again.X.data_ptr() == data.X.data_ptr()
+    # from device audio
+    so = np.concatenate([[0], np.cumsum(hg["sig_lengths"])])
+    audio = torch.as_tensor(hg["signals"], device=ctx.device)
+    labels, sc_dev, d2 = rec.recognize_device(models, audio, so, sr, dtype=dtype)
+    assert labels.is_cuda and labels.dtype == torch.int32 and sc_dev.is_cuda
+    assert np.array_equal(sc_dev.cpu().numpy(), scores)
+    assert [names[int(k)] for k in labels.cpu().numpy()] == pred == [str(l) for l in hg["labels"]]
+    # ties go to the first model in insertion order, as max(scores, key=scores.get) does
+    tie = torch.tensor([[1.0, 3.0, 3.0], [2.0, 2.0, 2.0], [-1.0, -2.0, -0.5], [float("-inf")] * 3],
+                       dtype=torch.float64, device=ctx.device)
+    assert sra.runtime.argmax_scores(ctx, tie).cpu().tolist() == [1, 0, 2, 0]
+
+
+def test_fit_from_device_features_equals_fit_from_host_features(sra, hg):
+    """MyGaussianHMM.fit on a device tensor (what train_hmm hands it) against the same fit on
+    the host copy of those features: same random draws, same rows as means, covariances from
+    the column-moments kernel equal to np.cov's diagonal to rounding, same history."""
+    import torch
+    ctx = sra.Context.default()
+    z = hg["z"]
+    lengths = [int(v) for v in hg["lengths"]]
+    for dtype, rt in (("float64", 1e-12), ("float32", 1e-6)):
+        a = sra.MyGaussianHMM(n_components=3, n_iter=6, tol=1e-9, verbose=False, random_state=3, dtype=dtype)
+        b = sra.MyGaussianHMM(n_components=3, n_iter=6, tol=1e-9, verbose=False, random_state=3, dtype=dtype)
+        np.random.seed(11)
+        a.fit(z, lengths)
+        np.random.seed(11)
+        b.fit(torch.as_tensor(z, device=ctx.device), lengths)
+        assert np.array_equal(a.means_, b.means_)
+        np.testing.assert_allclose(b._covars_, a._covars_, rtol=1e-13)
+        np.testing.assert_allclose(list(b.monitor_.history), list(a.monitor_.history), rtol=rt)
+        np.testing.assert_allclose(b.transmat_, a.transmat_, rtol=1e-6, atol=1e-12)
+    # the class-surface views of the packed statistics record
+    st = a.initialize_sufficient_statistics()
+    assert st["nobs"] == 0 and st["obs**2"].shape == (3, z.shape[1])
+    x0 = z[:lengths[0]]
+    a.accumulate_sufficient_statistics(st, x0)
+    one, _ = a.do_estep(x0, [lengths[0]])
+    assert st["nobs"] == 1 and np.array_equal(st["trans"], one["trans"])
+    np.testing.assert_allclose(a.compute_likelihood(x0), np.exp(a.compute_log_likelihood(x0)))
+    assert a.score_log(x0, compute_posteriors=False)[0] == a.score_scaling(x0, compute_posteriors=False)[0]

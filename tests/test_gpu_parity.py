@@ -885,10 +885,63 @@ def test_fused_estep_on_peaked_models(sra, ctx, S, D, spread, alpha, tol):
         np.testing.assert_allclose(g64[0][k], st[k], rtol=0, atol=1e-9 * max(1.0, np.abs(st[k]).max()))
 
 
+@pytest.mark.parametrize("eps", [1e-33, 1e-36, 3e-31])
+def test_fused_estep_rare_transition_with_dominant_emission(sra, ctx, eps):
+    """A state that the transition matrix reaches with probability ~1e-33 but whose emission
+    beats every other state's by e^104: the forward pass gives it alpha = 1, and the backward
+    pass of the fused float32 kernel, which divides alpha_t by the prediction A^T alpha_{t-1}
+    (here ~1e-33, far below any threshold that is safe to call "zero" short of the subnormal
+    range), has to carry it too.  Statistics and posteriors against the float64 kernels, and
+    those against the oracle."""
+    rng = np.random.default_rng(5)
+    S, D, U, m = 16, 13, 40, 4.0
+    pi = np.zeros(S); pi[0] = 1.0
+    A = np.eye(S)
+    A[0, 0], A[0, 1] = 1.0 - eps, eps
+    A[1, 0], A[1, 1] = 0.5, 0.5
+    means = rng.standard_normal((S, D)) * 0.01
+    means[1] += m
+    means[2:] -= 3 * m                       # unreachable states, far from every frame
+    prm = ho.Params(pi, A, means, np.ones((S, D)))
+    lengths = rng.integers(3, 60, size=U)
+    chunks = []
+    for T in lengths:
+        x = rng.standard_normal((T, D)) * 0.3
+        t0 = rng.integers(1, T)              # from here on the frames sit on state 1's mean for a while
+        x[t0:t0 + rng.integers(1, 6)] += m
+        chunks.append(x)
+    X = np.vstack(chunks)
+    bank = _bank(sra, ctx, [prm])
+    ctx.set_estep_path("fused")
+    try:
+        s32 = bank.estep(sra.Ragged(ctx, X, lengths, dtype="float32")).cpu().numpy()
+    finally:
+        ctx.set_estep_path("auto")
+    s64 = bank.estep(sra.Ragged(ctx, X, lengths, dtype="float64")).cpu().numpy()
+    assert np.isfinite(s32).all() and np.isfinite(s64).all()
+    g32, g64 = bank.unpack_stats(ctx.tensor(s32))[0], bank.unpack_stats(ctx.tensor(s64))[0]
+    st, lps = ho.estep(prm, X, [int(t) for t in lengths], loops=False)
+    assert abs(g64["logprob"] - float(np.sum(lps))) <= 1e-9 * abs(float(np.sum(lps)))
+    assert st["post"][1] > U                 # the rare state does hold the frames moved onto it
+    assert abs(g32["logprob"] - g64["logprob"]) <= 1e-5 * abs(g64["logprob"])
+    for k in ("start", "trans", "post", "obs", "obs**2"):
+        np.testing.assert_allclose(g64[k], st[k], rtol=0, atol=1e-9 * max(1.0, np.abs(st[k]).max()))
+        np.testing.assert_allclose(g32[k], g64[k], rtol=0, atol=1e-5 * np.abs(g64[k]).max(), err_msg=k)
+    lp32, p32 = bank.posteriors(sra.Ragged(ctx, X, lengths, dtype="float32"))
+    lp64, p64 = bank.posteriors(sra.Ragged(ctx, X, lengths, dtype="float64"))
+    p32, p64 = p32.cpu().numpy().astype(np.float64), p64.cpu().numpy()
+    assert np.isfinite(p32).all() and p64[:, 1].max() > 0.999
+    # (eps = 1e-36: a frame whose other state is 2^-135 of the rare one in density still has
+    # 2e-5 of the posterior in float64, but that ratio is below the smallest normal float32 and
+    # the float32 exponential returns zero for it: the range of the dtype, not of the division)
+    np.testing.assert_allclose(p32, p64, rtol=0, atol=1e-5 if eps > 1e-35 else 1e-4)
+    np.testing.assert_allclose(lp32.cpu().numpy(), lp64.cpu().numpy(), rtol=1e-5)
+
+
 @pytest.mark.parametrize("dtype,path", [("float32", "auto"), ("float64", "auto"), ("float32", "fused"),
                                         ("float64", "fused")])
 def test_estep_for_a_transitions_only_mstep(sra, ctx, dtype, path):
-    """SRX_OPT_ESTEP_STATS = transitions: count, log-probability, start and transition sums
+    """srx_estep_stats_select with SRX_STATS_TRANSITIONS: count, log-probability, start and transition sums
     are the ones of the full E-step bit for bit, the sums over the features complete or all
     zero (zero for a small job, which skips its pass over X), and the reference's M-step
     (start and transition probabilities only) gives the same parameters from either."""
@@ -905,11 +958,11 @@ def test_estep_for_a_transitions_only_mstep(sra, ctx, dtype, path):
     ctx.set_estep_path(path)
     try:
         full = bank.estep(data, umd).clone()
-        ctx.set_estep_stats("transitions")
-        part = bank.estep(data, umd).clone()
+        part = bank.estep(data, umd, stats="transitions").clone()
+        again = bank.estep(data, umd).clone()          # the selection does not outlive its call
     finally:
-        ctx.set_estep_stats("all")
         ctx.set_estep_path("auto")
+    assert again[:, 2:].abs().sum() > 0 and torch.allclose(again, full, rtol=1e-12, atol=0)
     gf, gp = bank.unpack_stats(full), bank.unpack_stats(part)
     for m in range(M):
         assert gp[m]["nobs"] == gf[m]["nobs"]

@@ -188,9 +188,6 @@ class _OracleBank:
             import torch
             return torch.from_numpy(np.ascontiguousarray(a))
 
-        def set_estep_stats(self, which):       # (the oracle-backed E-step computes everything)
-            assert which in ("all", "transitions")
-
     def __init__(self, params, X, lengths):
         from oracle import hmm_oracle as ho
         self.ho, self.ctx = ho, self._Ctx()
@@ -200,7 +197,8 @@ class _OracleBank:
         self.stats_size = 2 + self.S + self.S * self.S + self.S + 2 * self.S * self.D
         self.X, self.lengths = X, np.asarray(lengths)
 
-    def estep(self, data, utt_model, utt_order, out=None):
+    def estep(self, data, utt_model, utt_order, out=None, stats="all"):
+        assert stats in ("all", "transitions")     # (the oracle-backed E-step computes everything)
         ho = self.ho
         off = np.concatenate([[0], np.cumsum(self.lengths)])
         um = utt_model.numpy()

@@ -55,3 +55,44 @@ def test_static_entry_point_matches_forward_score():
     with pytest.raises(sra._lib.SrxError):
         small.score_static(d64, torch.empty((1, 2), dtype=torch.float64, device=ctx.device))
     ctx.close()
+
+
+def test_static_entry_point_on_two_streams():
+    """Two streams of one GPU share the fixed table array: calls that alternate between them,
+    each with another bank, are put in order by the library (the later stream waits for the
+    earlier call's kernels), so every call's scores are those of srx_forward_score."""
+    import torch
+    import speech_recognition_amd as sra
+
+    rng = np.random.default_rng(3)
+    ctx_ref = sra.Context.default()
+    D, U, T = 39, 4096, 100
+    X = rng.standard_normal((U * T, D)).astype(np.float32)
+    lengths = [T] * U
+    shapes = [(6, 8), (12, 8), (3, 16), (10, 3)]
+    ref_data = sra.Ragged(ctx_ref, X, lengths, dtype="float32")
+    want = []
+    for k, (M, S) in enumerate(shapes):
+        want.append(_bank(sra, ctx_ref, np.random.default_rng(50 + k), M, S, D).score(ref_data).cpu().numpy())
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ctxs, datas, banks, outs = [], [], [], []
+    for s in streams:
+        with torch.cuda.stream(s):
+            ctxs.append(sra.Context())
+            datas.append(sra.Ragged(ctxs[-1], X, lengths, dtype="float32"))
+    for k, (M, S) in enumerate(shapes):
+        c = ctxs[k % 2]
+        banks.append(_bank(sra, c, np.random.default_rng(50 + k), M, S, D))
+        outs.append(torch.full((U, M), float("nan"), dtype=torch.float64, device=c.device))
+    torch.cuda.synchronize()
+    for rep in range(3):                       # queued back to back, nothing waits in between
+        for k in range(len(shapes)):
+            with torch.cuda.stream(streams[k % 2]):
+                banks[k].score_static(datas[k % 2], outs[k])
+    torch.cuda.synchronize()
+    for k in range(len(shapes)):
+        assert np.array_equal(outs[k].cpu().numpy(), want[k]), k
+    for c in ctxs:
+        assert c.workspace_bytes() == 0
+        c.close()

@@ -24,18 +24,17 @@ um = torch.as_tensor(um_host, dtype=torch.int32, device='cuda')
 order = None
 if os.environ.get("ES_ORDER") == "memory":
     order = torch.as_tensor(np.argsort(um_host, kind="stable").astype(np.int64), device='cuda')
-if os.environ.get("ES_STATS"):          # "transitions": the E-step of a transitions-only M-step
-    ctx.set_estep_stats(os.environ["ES_STATS"])
+which = os.environ.get("ES_STATS", "all")   # "transitions": the E-step of a transitions-only M-step
 out = None
 for _ in range(6):
-    out = bank.estep(data, um, order, out=out)
+    out = bank.estep(data, um, order, out=out, stats=which)
 torch.cuda.synchronize()
 ts = []
 for _ in range(5):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(4):
-        out = bank.estep(data, um, order, out=out)
+        out = bank.estep(data, um, order, out=out, stats=which)
     e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1) / 4)
 st = out.cpu().numpy()
