@@ -74,6 +74,22 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Diagnostic build only (-DSRX_MFCC_STAMPS, never in libsrx.so proper): cycles a wave spends in
+// each phase of a step, summed over all waves into g_stamps[phase] (and the number of steps into
+// g_stamps[15]); srx_debug_mfcc_stamps copies the sums to the host and clears them.  The stamps
+// go to this array only; no output value depends on them.
+#ifdef SRX_MFCC_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP(i)                                                   \
+    do {                                                           \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
+        st_acc[i] += now__ - st_last;                              \
+        st_last = now__;                                           \
+    } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 constexpr int brev(int i, int bits) {
     int r = 0;
@@ -155,6 +171,55 @@ __device__ __forceinline__ void fft_regs(v2f (&z)[Q]) {
     }
 }
 
+// The same transforms on separate real and imaginary registers with plain (one value per lane)
+// instructions.  A packed instruction costs two plain ones in issue time, so the arithmetic is
+// priced alike, but plain operands may sit in any register: none of the moves that line pairs
+// up for the packed forms, sign changes and half swaps are free (operand order, v_sub, negated
+// fma operands), and a twiddle of (1 -+ i) / sqrt 2 is two additions and four fused
+// multiply-adds instead of a full complex product.
+struct cf {
+    float x, y;
+};
+
+template <int Q>
+__device__ __forceinline__ void fft_regs(cf (&z)[Q]) {
+#pragma unroll
+    for (int s = 1; s <= ilog2(Q); ++s) {
+        const int m = 1 << s, half = m >> 1, tstep = Q / m;
+#pragma unroll
+        for (int k = 0; k < Q; k += m) {
+#pragma unroll
+            for (int jj = 0; jj < half; ++jj) {
+                const int i0 = k + jj, i1 = i0 + half;
+                const cf a = z[i0], b = z[i1];
+                if (jj == 0) {
+                    z[i0] = cf{a.x + b.x, a.y + b.y};
+                    z[i1] = cf{a.x - b.x, a.y - b.y};
+                } else if (2 * jj == half) {     // W = -i: t = (b.y, -b.x)
+                    z[i0] = cf{a.x + b.y, a.y - b.x};
+                    z[i1] = cf{a.x - b.y, a.y + b.x};
+                } else if (4 * jj == half) {     // W = (1 - i) / sqrt 2: t = c (b.x + b.y, b.y - b.x)
+                    const float c = 0.7071067690849304f;
+                    const float u = b.x + b.y, v = b.y - b.x;
+                    z[i0] = cf{fmaf(c, u, a.x), fmaf(c, v, a.y)};
+                    z[i1] = cf{fmaf(-c, u, a.x), fmaf(-c, v, a.y)};
+                } else if (4 * jj == 3 * half) { // W = (-1 - i) / sqrt 2: t = c (b.y - b.x, -(b.x + b.y))
+                    const float c = 0.7071067690849304f;
+                    const float u = b.y - b.x, v = b.x + b.y;
+                    z[i0] = cf{fmaf(c, u, a.x), fmaf(-c, v, a.y)};
+                    z[i1] = cf{fmaf(-c, u, a.x), fmaf(c, v, a.y)};
+                } else {
+                    const int q32 = jj * tstep * (32 / Q);      // folds to a constant once unrolled
+                    const float wr = kCos32[q32], wi = kSin32[q32];
+                    // t = (wr b.x - wi b.y, wr b.y + wi b.x), a +- t as chains of two fma each
+                    z[i0] = cf{fmaf(wr, b.x, fmaf(-wi, b.y, a.x)), fmaf(wr, b.y, fmaf(wi, b.x, a.y))};
+                    z[i1] = cf{fmaf(-wr, b.x, fmaf(wi, b.y, a.x)), fmaf(-wr, b.y, fmaf(-wi, b.x, a.y))};
+                }
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ int64_t raw_frames(int64_t n, int L, int hop) {
     return n < L ? 0 : (n - L) / hop + 1;
 }
@@ -175,6 +240,46 @@ __global__ __launch_bounds__(256) void row_start_kernel(const int64_t* __restric
         for (unsigned t = lane; t < T; t += 64) row_start[row0 + t] = (int32_t)((unsigned)us + t * hop);
     }
 }
+
+// Y = W z for the transpose tile (unit: W is 1)
+__device__ __forceinline__ v2f twiddled(v2f w, v2f z, bool) { return cmul_v(w, z); }
+__device__ __forceinline__ v2f twiddled(v2f w, cf z, bool unit) {
+    return unit ? v2f{z.x, z.y} : v2f{fmaf(w.x, z.x, -w.y * z.y), fmaf(w.x, z.y, w.y * z.x)};
+}
+// Real-input unpack of the bin pair (k, H - k) from zk = Z[k], zc = Z[H-k] and w = W_N^k:
+// with E = (Z[k] + conj Z[H-k]) / 2 and O = -i (Z[k] - conj Z[H-k]) / 2, X[k] = E + W^k O and
+// X[H-k] = conj(E - W^k O); the halves are left to `scale` (|2X|^2 / 4).
+__device__ __forceinline__ void power_pair(v2f zk, v2f zc, v2f w, float scale, float& pk, float& pc) {
+    v2f e2, dd, t1, pp;
+    // e2 = Z[k] + conj Z[H-k], dd = Z[k] - conj Z[H-k]
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(e2) : "v"(zk), "v"(zc));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(dd) : "v"(zk), "v"(zc));
+    // pp = W^k (dd.y, -dd.x) = (w.x dd.y + w.y dd.x, w.y dd.y - w.x dd.x)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t1) : "v"(w), "v"(dd));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[0,0,0] neg_hi:[0,1,0]"
+        : "=v"(pp) : "v"(w), "v"(dd), "v"(t1));
+    const v2f xa = e2 + pp, xb = e2 - pp;
+    const v2f qa = xa * xa, qb = xb * xb;
+    pk = (qa.x + qa.y) * scale;
+    pc = (qb.x + qb.y) * scale;
+}
+__device__ __forceinline__ void power_pair(cf zk, cf zc, v2f w, float scale, float& pk, float& pc) {
+    const float ex = zk.x + zc.x, ey = zk.y - zc.y, dx = zk.x - zc.x, dy = zk.y + zc.y;
+    const float px = fmaf(w.x, dy, w.y * dx), py = fmaf(w.y, dy, -w.x * dx);
+    const float ax = ex + px, ay = ey + py, bx = ex - px, by = ey - py;
+    pk = fmaf(ax, ax, ay * ay) * scale;
+    pc = fmaf(bx, bx, by * by) * scale;
+}
+
+// Which of the two forms the transform kernel uses (both are kept: the packed one is the
+// measured baseline of the other).
+#ifdef SRX_MFCC_PACKED
+constexpr bool kScalarFft = false;
+typedef v2f cpx;
+#else
+constexpr bool kScalarFft = true;
+typedef cf cpx;
+#endif
 
 template <int P>
 __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_fast_kernel(
@@ -218,7 +323,11 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
     // stage 5 sees the wave's 4 frames as columns: lane (block b, column r)
     float* wfr = s_frames + (size_t)(4 * wave) * per_frame;
     const int blk = lane >> 2, col = lane & 3;
+#ifdef SRX_X1
+    const float* pw_col = wfr + kPw;
+#else
     const float* pw_col = wfr + (size_t)col * per_frame + kPw;
+#endif
     float* lm_col = wfr + (size_t)col * per_frame + kLm;                  // [4 kk]
     // partial sums of block b, column r: 4 floats in the tile of frame b / 4
     auto part_at = [&](int b, int r) {
@@ -237,6 +346,11 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
     const int64_t b_begin = (int64_t)blockIdx.x * per_block;
     const int64_t b_end = b_begin + per_block < n_chunks ? b_begin + per_block : n_chunks;
     if (b_begin >= b_end) return;
+#ifdef SRX_MFCC_STAMPS
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+    unsigned long long st_steps = 0;
+#endif
     const unsigned hop = (unsigned)c.hop;
     // start sample of this lane group's row in step bq (-1: none)
     auto row_of = [&](int64_t bq) { return bq * FB + item; };
@@ -274,31 +388,45 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
     // one step: the frames whose samples are in xc (start sample `start`, row `row`)
     auto transform = [&](int start, int64_t row, const float (&xc)[2 * P]) {
         const bool have = start >= 0;
+        STAMP(0);
+#ifdef SRX_MFCC_STAMPS
+        ++st_steps;
+#endif
         // ---- 1. window, bit-reversed register order, P-point FFT over n1
         const bool any = __ballot(have) != 0;     // no frame starts in this chunk for this wave?
-        v2f z1[P];
+        cpx z1[P];
 #pragma unroll
         for (int n1 = 0; n1 < P; ++n1) {
             const int i0 = 32 * n1 + 2 * j;
+#ifdef SRX_X2
+            const float2 wv = float2{0.5f, 0.25f};
+#else
             const float2 wv = *(const float2*)(s_win + i0);
-            z1[brev(n1, ilog2(P))] = v2f{mul_zero_wins(xc[2 * n1], wv.x), mul_zero_wins(xc[2 * n1 + 1], wv.y)};
+#endif
+            z1[brev(n1, ilog2(P))] = cpx{mul_zero_wins(xc[2 * n1], wv.x), mul_zero_wins(xc[2 * n1 + 1], wv.y)};
         }
         if (any) {
         fft_regs<P>(z1);
+        STAMP(1);
         // ---- 2. twiddle W_H^(j k1) and 3. transpose through LDS: Y[k1][j]
 #pragma unroll
-        for (int k1 = 0; k1 < P; ++k1) Y[k1 * 17 + j] = cmul_v(s_tw2[k1 * 16 + j], z1[k1]);
+        for (int k1 = 0; k1 < P; ++k1) Y[k1 * 17 + j] = twiddled(s_tw2[k1 * 16 + j], z1[k1], k1 == 0);
         wave_sync();
-        v2f z2[KB][16];
+        cpx z2[KB][16];
 #pragma unroll
         for (int i = 0; i < KB; ++i) {
             const int k1 = j + 16 * i;
 #pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) z2[i][brev(n2, 4)] = Y[k1 * 17 + n2];
+            for (int n2 = 0; n2 < 16; ++n2) {
+                const v2f y = Y[k1 * 17 + n2];
+                z2[i][brev(n2, 4)] = cpx{y.x, y.y};
+            }
         }
         wave_sync();
+        STAMP(2);
 #pragma unroll
         for (int i = 0; i < KB; ++i) fft_regs<16>(z2[i]);
+        STAMP(3);
         // ---- 4. real-input spectrum, power / N.  Bins k and H-k share their inputs.  Lane j now
         // holds Z[j + 16 m], m < P (m = KB k2 + i).  Its bins k = j + 16 mm, mm < P/2, are its
         // own lower half; their partners H - k = (16 - j) + 16 (P - 1 - mm) are the UPPER half of
@@ -311,23 +439,24 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
 #pragma unroll
         for (int u = 0; u < P / 2; u += 2) {
             const int m0 = u + P / 2, m1 = m0 + 1;
-            const v2f a = z2[m0 % KB][m0 / KB], b = z2[m1 % KB][m1 / KB];
+            const cpx a = z2[m0 % KB][m0 / KB], b = z2[m1 % KB][m1 / KB];
             *(f32x4*)(slots + j * LT + 2 * u) = f32x4{a.x, a.y, b.x, b.y};
         }
         wave_sync();
         const float quarter_inv_n = 0.25f / (float)N;
-        v2f zks[P / 2], zcs[P / 2];
+        cpx zks[P / 2], zcs[P / 2];
         {
             const int jp = (16 - j) & 15;
             const float* sp = slots + jp * LT + (j == 0 ? 2 : 0);
 #pragma unroll
             for (int mm = 0; mm < P / 2; ++mm) {
                 zks[mm] = z2[mm % KB][mm / KB];
-                zcs[mm] = *(const v2f*)(sp + 2 * (P / 2 - 1 - mm));
+                const v2f t = *(const v2f*)(sp + 2 * (P / 2 - 1 - mm));
+                zcs[mm] = cpx{t.x, t.y};
             }
             if (j == 0) zcs[0] = z2[0][0];
         }
-        const v2f zh = z2[0][8];                  // Z[H/2], lane 0's (the only lane that uses it)
+        const cpx zh = z2[0][8];                  // Z[H/2], lane 0's (the only lane that uses it)
         wave_sync();                              // the slots are in registers: pw may take their place
 #pragma unroll
         for (int mm = 0; mm < P / 2; ++mm) {
@@ -335,25 +464,14 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
             // with E = (Z[k] + conj Z[H-k]) / 2 and O = -i (Z[k] - conj Z[H-k]) / 2:
             // X[k] = E + W^k O ;  X[H-k] = conj(E - W^k O).  The halves are left out
             // until the end (|2X|^2 / 4).
-            v2f e2, dd, t1, pp;
-            // e2 = Z[k] + conj Z[H-k], dd = Z[k] - conj Z[H-k]
-            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(e2) : "v"(zks[mm]), "v"(zcs[mm]));
-            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(dd) : "v"(zks[mm]), "v"(zcs[mm]));
-            // pp = W^k (dd.y, -dd.x) = (w.x dd.y + w.y dd.x, w.y dd.y - w.x dd.x)
-            const v2f w = s_tw[k];
-            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t1) : "v"(w), "v"(dd));
-            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[0,0,0] neg_hi:[0,1,0]"
-                : "=v"(pp) : "v"(w), "v"(dd), "v"(t1));
-            const v2f xa = e2 + pp, xb = e2 - pp;
-            const v2f qa = xa * xa, qb = xb * xb;
-            pw[k] = (qa.x + qa.y) * quarter_inv_n;
-            pw[H - k] = (qb.x + qb.y) * quarter_inv_n;
+            power_pair(zks[mm], zcs[mm], s_tw[k], quarter_inv_n, pw[k], pw[H - k]);
         }
         if (j == 0) {   // k = H/2 is its own partner: E = (zr, 0), O = (zi, 0), W^(H/2) = -i
             pw[H / 2] = (zh.x * zh.x + zh.y * zh.y) * (4.f * quarter_inv_n);
         }
         if (j < 3) pw[H + 1 + j] = 0.f;           // padding that meets zero weights: keep it finite
         wave_sync();
+        STAMP(4);
         // ---- 5. mel energies: block `blk` adds its range of bins for 4 filters x 4 frames
         {
             // four accumulators, one per bin of a quad: a 4x4x1 product waits for the one before
@@ -388,6 +506,7 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
             *(f32x4*)part_at(blk, col) = acc;
         }
         wave_sync();
+        STAMP(5);
         // blocks of one group of filters add up; exact zeros -> eps; log_mult * log10
         // log_mult * log10(2) as a float and the part of it the float misses
         const double scale_d = (double)c.log_mult * 0.30102999566398120;
@@ -410,6 +529,7 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
             *(f32x4*)(lm_col + 4 * blk) = f32x4{0.f, 0.f, 0.f, 0.f};      // padding of the log-mel row
         }
         wave_sync();
+        STAMP(6);
         // ---- DCT-II rows: 4 cepstra x 4 frames per block, over one slice of the filters
         {
             f32x4 ac[4];
@@ -447,6 +567,7 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
             }
         }
         wave_sync();
+        STAMP(7);
         }   // any
     };
     // two steps per trip so that the two sample buffers swap roles without copies
@@ -464,6 +585,12 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
         s0 = s2;
         s1 = s3;
     }
+#ifdef SRX_MFCC_STAMPS
+    if (lane == 0) {
+        for (int i = 0; i < 10; ++i) atomicAdd(&g_stamps[i], st_acc[i]);
+        atomicAdd(&g_stamps[15], st_steps);
+    }
+#endif
 }
 
 template <int P>
@@ -507,6 +634,16 @@ int launch_fast(srx_context* h, const float* audio, const int64_t* so, int64_t U
 }
 
 }  // namespace
+
+#ifdef SRX_MFCC_STAMPS
+extern "C" int srx_debug_mfcc_stamps(unsigned long long* out16) {
+    SRX_HIP(hipDeviceSynchronize());
+    SRX_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16));
+    unsigned long long zero[16] = {};
+    SRX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof(zero)));
+    return SRX_OK;
+}
+#endif
 
 int srx_mfcc_fast_cepstra(srx_context* h, srx_mfcc_plan* p, const float* audio, const int64_t* so,
                           int64_t U, int64_t total, float* cep, hipStream_t st) {
