@@ -16,7 +16,10 @@ SOURCES = ["api.hip", "hmm_generic.hip", "score_mfma.hip", "score_split8.hip", "
 # multiplies) issue slower than the two plain ones beside matrix instructions.
 FILE_FLAGS = {"score_mfma.hip": ["-fno-slp-vectorize"], "score_split8.hip": ["-fno-slp-vectorize"],
               "score_split4.hip": ["-fno-slp-vectorize"], "score_split16.hip": ["-fno-slp-vectorize"],
-              "viterbi_fused.hip": ["-fno-slp-vectorize"]}
+              "viterbi_fused.hip": ["-fno-slp-vectorize"],
+              # (the 512-point transform is written on plain registers: re-packed by the
+              # vectoriser it needs a move per pair and runs 7 % slower)
+              "mfcc_fast.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall",
          "-Wno-unused-function", "-fvisibility=default",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC]

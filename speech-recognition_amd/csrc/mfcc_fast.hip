@@ -20,7 +20,7 @@
 //      plan: weights per (quad, lane), first bin per block).  Blocks that share
 //      filters add up through LDS; log10; the DCT's 16 blocks are 4 groups of
 //      cepstra x 4 slices of the filters, added across lanes at the end.
-// A wave carries 4 frames at once, a workgroup 16 (12 in the 1024-point kernel).  Cepstra
+// A wave carries 4 frames at once, a workgroup 16.  Cepstra
 // rows live on the packed sample axis exactly as in the generic kernel (mfcc.hip): frame t
 // of an utterance that starts at sample s0 is row s0 / hop + t.  A small kernel first writes,
 // for every row, the sample its frame starts at (-1: no frame there); the transform kernel
@@ -32,9 +32,8 @@
 namespace {
 
 constexpr int kWave = 64;
-// Frames a workgroup transforms at once (4 per wave).  The 1024-point kernel takes 12:
-// two workgroups of it fit the LDS of a CU, one of 16 frames would be alone.
-template <int P> constexpr int frames_per_block() { return P == 16 ? 16 : 12; }
+// Frames a workgroup transforms at once (4 per wave).
+template <int P> constexpr int frames_per_block() { return 16; }
 
 struct FastDev {
     int frame_len, hop, n_used, n_mel, n_ceps, nnz;
@@ -271,18 +270,29 @@ __device__ __forceinline__ void power_pair(cf zk, cf zc, v2f w, float scale, flo
     pc = fmaf(bx, bx, by * by) * scale;
 }
 
-// Which of the two forms the transform kernel uses (both are kept: the packed one is the
-// measured baseline of the other).
-#ifdef SRX_MFCC_PACKED
-constexpr bool kScalarFft = false;
-typedef v2f cpx;
-#else
-constexpr bool kScalarFft = true;
-typedef cf cpx;
-#endif
+// Per transform size, what measured fastest (8192 x 3 s of audio, whole front-end pass):
+//   512 points   plain-register arithmetic (1.16 ms against 1.19 packed), mel / DCT tables in LDS
+//                (from global memory, which would make room for a fourth workgroup per CU: 1.22),
+//                16 frames per workgroup, three workgroups per CU
+//   1024 points  packed arithmetic (2.43 ms against 2.63 plain: 210 against 186 registers, two
+//                waves per SIMD either way), mel / DCT tables read from global memory (11 KB that
+//                every workgroup reads at the same addresses: they live in the vector cache),
+//                which lets a workgroup take 16 frames instead of 12 with two workgroups per CU
+//                (2.77 ms with 12 frames and the tables in LDS)
+template <int P> struct FastCfg {
+    typedef cf cpx;
+    static constexpr bool lds_weights = true;
+};
+template <> struct FastCfg<32> {
+    typedef v2f cpx;
+    static constexpr bool lds_weights = false;
+};
+
+// Workgroups a CU holds at once (registers and LDS are sized for it)
+template <int P> constexpr int kWgPerCu = P == 16 ? 3 : 2;
 
 template <int P>
-__global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_fast_kernel(
+__global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * frames_per_block<P>() + 255) / 256) void cepstra_fast_kernel(
     const float* __restrict__ audio, const int32_t* __restrict__ row_start, int64_t n_rows, int64_t total,
     FastDev c, float* __restrict__ cep) {
     constexpr int H = 16 * P, N = 2 * H, KB = P / 16;   // KB 16-point FFTs per lane in step 3
@@ -291,9 +301,17 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
     // ---- shared tables
     v2f* s_tw = (v2f*)smem_raw;                       // [H/2]: exp(-2 pi i k / N)
     float* s_win = (float*)(s_tw + H / 2);                  // [N], zero past the samples the FFT uses
-    float* s_w4 = s_win + N;                                // [nq][64][4]
-    float* s_dctA = s_w4 + (size_t)c.nq * 256;              // [64][kk]
-    int* s_meta = (int*)(s_dctA + 64 * c.kk);               // [48]
+    typedef typename FastCfg<P>::cpx cpx;
+    constexpr bool kLdsW = FastCfg<P>::lds_weights;
+    float* s_w4_lds = s_win + N;                            // [nq][64][4]
+    float* s_dctA_lds = s_w4_lds + (size_t)c.nq * 256;      // [64][kk]
+    const float* s_w4 = kLdsW ? s_w4_lds : c.mm_w;
+    const float* s_dctA = kLdsW ? s_dctA_lds : c.mm_dct;
+    int* s_meta = kLdsW ? (int*)(s_dctA_lds + 64 * c.kk) : (int*)(s_win + N);   // [48]
+    if constexpr (kLdsW) {
+        for (int i = threadIdx.x; i < c.nq * 256; i += blockDim.x) s_w4_lds[i] = c.mm_w[i];
+        for (int i = threadIdx.x; i < 64 * c.kk; i += blockDim.x) s_dctA_lds[i] = c.mm_dct[i];
+    }
     v2f* s_tw2 = (v2f*)(s_meta + 48);                 // [P][16]: W_H^(j k1)
     float* s_frames = (float*)(s_tw2 + P * 16);
     // A frame's tile holds the transpose buffer Y / the spectrum Z first; once Z has
@@ -304,8 +322,6 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
     const int part_off = kLm + 4 * c.kk;
     for (int i = threadIdx.x; i < H / 2; i += blockDim.x) s_tw[i] = v2f{c.tw[i].x, c.tw[i].y};
     for (int i = threadIdx.x; i < N; i += blockDim.x) s_win[i] = i < c.n_used ? c.window[i] : 0.f;
-    for (int i = threadIdx.x; i < c.nq * 256; i += blockDim.x) s_w4[i] = c.mm_w[i];
-    for (int i = threadIdx.x; i < 64 * c.kk; i += blockDim.x) s_dctA[i] = c.mm_dct[i];
     for (int i = threadIdx.x; i < 48; i += blockDim.x) s_meta[i] = c.mm_meta[i];
     for (int i = threadIdx.x; i < P * 16; i += blockDim.x)
     {
@@ -323,11 +339,7 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
     // stage 5 sees the wave's 4 frames as columns: lane (block b, column r)
     float* wfr = s_frames + (size_t)(4 * wave) * per_frame;
     const int blk = lane >> 2, col = lane & 3;
-#ifdef SRX_X1
-    const float* pw_col = wfr + kPw;
-#else
     const float* pw_col = wfr + (size_t)col * per_frame + kPw;
-#endif
     float* lm_col = wfr + (size_t)col * per_frame + kLm;                  // [4 kk]
     // partial sums of block b, column r: 4 floats in the tile of frame b / 4
     auto part_at = [&](int b, int r) {
@@ -386,7 +398,9 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
         }
     };
     // one step: the frames whose samples are in xc (start sample `start`, row `row`)
-    auto transform = [&](int start, int64_t row, const float (&xc)[2 * P]) {
+    // (the samples are dead once the window has been applied: the next step's are requested
+    // into the same registers right there, a whole step before they are used)
+    auto transform = [&](int start, int64_t row, float (&xc)[2 * P], int next_start, int64_t next_b) {
         const bool have = start >= 0;
         STAMP(0);
 #ifdef SRX_MFCC_STAMPS
@@ -398,13 +412,10 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
 #pragma unroll
         for (int n1 = 0; n1 < P; ++n1) {
             const int i0 = 32 * n1 + 2 * j;
-#ifdef SRX_X2
-            const float2 wv = float2{0.5f, 0.25f};
-#else
             const float2 wv = *(const float2*)(s_win + i0);
-#endif
             z1[brev(n1, ilog2(P))] = cpx{mul_zero_wins(xc[2 * n1], wv.x), mul_zero_wins(xc[2 * n1 + 1], wv.y)};
         }
+        fetch(next_start, next_b, xc);
         if (any) {
         fft_regs<P>(z1);
         STAMP(1);
@@ -570,20 +581,14 @@ __global__ __launch_bounds__(P == 16 ? 256 : 192, P == 16 ? 3 : 2) void cepstra_
         STAMP(7);
         }   // any
     };
-    // two steps per trip so that the two sample buffers swap roles without copies
-    float xa[2 * P], xb[2 * P];
+    float x[2 * P];
     int s0 = load_start(b_begin), s1 = load_start(b_begin + 1);
-    fetch(s0, b_begin, xa);
-    for (int64_t b = b_begin; b < b_end; b += 2) {
-        fetch(s1, b + 1 < b_end ? b + 1 : b, xb);    // (the last step's repeat is harmless)
+    fetch(s0, b_begin, x);
+    for (int64_t b = b_begin; b < b_end; ++b) {
         const int s2 = load_start(b + 2);
-        transform(s0, row_of(b), xa);
-        if (b + 1 >= b_end) break;
-        fetch(s2, b + 2 < b_end ? b + 2 : b + 1, xa);
-        const int s3 = load_start(b + 3);
-        transform(s1, row_of(b + 1), xb);
-        s0 = s2;
-        s1 = s3;
+        transform(s0, row_of(b), x, s1, b + 1 < b_end ? b + 1 : b);   // (the last step's repeat is harmless)
+        s0 = s1;
+        s1 = s2;
     }
 #ifdef SRX_MFCC_STAMPS
     if (lane == 0) {
@@ -597,8 +602,8 @@ template <int P>
 int launch_fast(srx_context* h, const float* audio, const int64_t* so, int64_t U, int64_t total,
                 const FastDev& d, float* cep, hipStream_t st) {
     constexpr int H = 16 * P, N = 2 * H, YS = P * 17;
-    const size_t tables = sizeof(float2) * (H / 2) + sizeof(float2) * P * 16 +
-                          4 * ((size_t)N + (size_t)d.nq * 256 + 64 * (size_t)d.kk + 48);
+    const size_t tables = sizeof(float2) * (H / 2) + sizeof(float2) * P * 16 + 4 * ((size_t)N + 48) +
+                          (FastCfg<P>::lds_weights ? 4 * ((size_t)d.nq * 256 + 64 * (size_t)d.kk) : 0);
     const size_t per_frame = 4 * (size_t)2 * YS;
     if ((size_t)(H + 4) + 4 * (size_t)d.kk + 64 > (size_t)2 * YS) return SRX_EUNSUPPORTED;
     const size_t lds = tables + per_frame * frames_per_block<P>();
@@ -622,8 +627,7 @@ int launch_fast(srx_context* h, const float* audio, const int64_t* so, int64_t U
     const int64_t n_chunks = (n_rows + frames_per_block<P>() - 1) / frames_per_block<P>();
     // four rounds of the workgroups that fit a CU at once (LDS decides)
     int per_cu = (int)((160 * 1024) / lds);
-    per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
-    if (P != 16 && per_cu > 2) per_cu = 2;
+    per_cu = per_cu < 1 ? 1 : (per_cu > kWgPerCu<P> ? kWgPerCu<P> : per_cu);
     const int64_t want = (int64_t)h->n_cu * per_cu * 4;
     int64_t grid = n_chunks < want ? n_chunks : want;
     if (grid < 1) grid = 1;

@@ -9,7 +9,7 @@ CS=$ROOT/speech-recognition_amd/csrc
 mkdir -p $ROOT/build_variants
 OBJ=$ROOT/build_variants/${NAME}_$(basename ${SRC%.hip}).o
 EXTRA=""
-case $(basename $SRC) in score_*|viterbi_fused.hip) EXTRA="-fno-slp-vectorize";; esac
+case $(basename $SRC) in score_*|viterbi_fused.hip|mfcc_fast.hip) EXTRA="-fno-slp-vectorize";; esac
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function -fvisibility=default \
     -I $ROOT/include -I $CS $EXTRA "$@" -c $CS/$(basename $SRC) -o $OBJ
 OTHERS=$(ls $CS/*.o | grep -v "/$(basename ${SRC%.hip}).o")
