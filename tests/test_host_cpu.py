@@ -175,6 +175,22 @@ def test_bench_launcher_starts_one_rank_per_gpu():
     assert r.returncode == 0 and len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1
 
 
+def test_two_rank_bench_record():
+    """The kept line of `bench.py --gpus 2 --share-gpu --backend gloo` (two ranks sharing the
+    one GPU of a test box, profiles/r3_two_rank_rehearsal_gloo.json): the N > 1 branch ran, its
+    line carries the training metric with the rank count an all-reduce returned, and the
+    all-reduced statistics of the two shards equal one rank's E-step over all utterances."""
+    import json
+    with open(os.path.join(ROOT, "profiles", "r3_two_rank_rehearsal_gloo.json")) as f:
+        d = json.load(f)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["collective_backend"] == "gloo"
+    assert d["metric"] == "hmm_scored_frames_per_sec_6_models" and d["scaling"] == "weak"
+    for key in ("baum_welch_iter_per_s", "allreduce_ms_per_iter", "value", "ms_per_step"):
+        assert isinstance(d[key], float) and d[key] > 0, key
+    assert d["extra"]["baum_welch"]["rccl_ranks"] == 2
+    assert 0 <= d["sharded_vs_single_rank_stats_max_rel_err"] < 1e-5
+
+
 class _OracleBank:
     """Stand-in for HMMBank on a machine without a GPU: the same methods the trainer calls,
     with the CPU oracle in place of the kernels and CPU tensors in place of device memory."""
