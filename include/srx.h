@@ -115,8 +115,11 @@ int srx_destroy(srx_handle_t h);
  * exact-f32 matrix instructions; the default (0) evaluates the emission
  * contraction with split-bf16 operands (three partial products, error ~1e-6
  * relative on a log-likelihood), which is several times faster.
- * SRX_OPT_ESTEP_PATH chooses the kernels of the SRX_F32 E-step: SRX_ESTEP_AUTO (0,
- * default) takes one lane per utterance for small jobs (at most 8 states and, by the
+ * SRX_OPT_ESTEP_PATH chooses the kernels of the E-step: SRX_ESTEP_AUTO (0, default) takes
+ * one WAVE per utterance for the smallest jobs (at most 2048 utterances and 4 states, either
+ * dtype: the reference's own training runs; SRX_ESTEP_WAVE (3) asks for it wherever those
+ * limits allow, the other values never take it), then for SRX_F32
+ * one lane per utterance for small jobs (at most 8 states and, by the
  * number of states, 3072 to 8192 utterances) and the fused matrix-core kernel otherwise; SRX_ESTEP_FUSED (1) and
  * SRX_ESTEP_LANE (2) ask for one of the two wherever its limits allow (tests, timing).
  * The results agree to float32 rounding.  SRX_F64 data: small jobs take one lane per
@@ -134,7 +137,7 @@ enum srx_option { SRX_OPT_EXACT_F32 = 1, SRX_OPT_ESTEP_PATH = 2, SRX_OPT_VITERBI
  * SRX_MSTEP_TRANSITIONS_ONLY mode).  The post, obs and obs2 entries of the records are then
  * all zero: the kernels leave out their pass over the features. */
 enum srx_estep_stats { SRX_STATS_ALL = 0, SRX_STATS_TRANSITIONS = 1 };
-enum srx_estep_path { SRX_ESTEP_AUTO = 0, SRX_ESTEP_FUSED = 1, SRX_ESTEP_LANE = 2 };
+enum srx_estep_path { SRX_ESTEP_AUTO = 0, SRX_ESTEP_FUSED = 1, SRX_ESTEP_LANE = 2, SRX_ESTEP_WAVE = 3 };
 enum srx_viterbi_path { SRX_VITERBI_AUTO = 0, SRX_VITERBI_FUSED = 1, SRX_VITERBI_SPLIT = 2 };
 int srx_set_option(srx_handle_t h, int option, int value);
 /* Bytes of scratch currently held by the context (diagnostics). */

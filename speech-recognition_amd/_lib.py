@@ -21,7 +21,7 @@ SRX_OPT_ESTEP_PATH = 2
 SRX_OPT_VITERBI_PATH = 3
 SRX_VITERBI_AUTO, SRX_VITERBI_FUSED, SRX_VITERBI_SPLIT = 0, 1, 2
 SRX_STATS_ALL, SRX_STATS_TRANSITIONS = 0, 1
-SRX_ESTEP_AUTO, SRX_ESTEP_FUSED, SRX_ESTEP_LANE = 0, 1, 2
+SRX_ESTEP_AUTO, SRX_ESTEP_FUSED, SRX_ESTEP_LANE, SRX_ESTEP_WAVE = 0, 1, 2, 3
 SRX_EINVAL, SRX_EHIP, SRX_ENOMEM, SRX_EUNSUPPORTED = -1, -2, -3, -4
 
 

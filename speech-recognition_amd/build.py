@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsrx.so")
-SOURCES = ["api.hip", "hmm_generic.hip", "score_mfma.hip", "score_split8.hip", "score_split4.hip", "score_split16.hip", "score_f64.hip", "estep_fused.hip", "viterbi_fused.hip", "mfcc.hip", "mfcc_fast.hip", "large_model.hip", "endpoint.hip", "pipeline.hip"]
+SOURCES = ["api.hip", "hmm_generic.hip", "score_mfma.hip", "score_split8.hip", "score_split4.hip", "score_split16.hip", "score_f64.hip", "estep_fused.hip", "viterbi_fused.hip", "mfcc.hip", "mfcc_fast.hip", "large_model.hip", "endpoint.hip", "pipeline.hip", "estep_wave.hip"]
 # Packed f32 vector instructions (what SLP vectorisation makes of adjacent adds and
 # multiplies) issue slower than the two plain ones beside matrix instructions.
 FILE_FLAGS = {"score_mfma.hip": ["-fno-slp-vectorize"], "score_split8.hip": ["-fno-slp-vectorize"],

@@ -158,7 +158,7 @@ int srx_set_option(srx_handle_t h, int option, int value) {
     switch (option) {
         case SRX_OPT_EXACT_F32: h->exact_f32 = value != 0; return SRX_OK;
         case SRX_OPT_ESTEP_PATH:
-            SRX_REQUIRE(value >= SRX_ESTEP_AUTO && value <= SRX_ESTEP_LANE, "srx_set_option: unknown E-step path %d", value);
+            SRX_REQUIRE(value >= SRX_ESTEP_AUTO && value <= SRX_ESTEP_WAVE, "srx_set_option: unknown E-step path %d", value);
             h->estep_path = value;
             return SRX_OK;
         case SRX_OPT_VITERBI_PATH:
@@ -441,6 +441,12 @@ static int estep_common(srx_handle_t h, const void* X, int dtype, const int64_t*
     // (a property of this call, not of the context: every E-step call writes it before any
     // kernel of that call is chosen, and nothing else reads it)
     h->estep_stats = which_stats;
+    if (allow_fused && (h->estep_path == SRX_ESTEP_AUTO || h->estep_path == SRX_ESTEP_WAVE)) {
+        // the smallest jobs (the reference's own size): one wave per utterance
+        rc = srx_wave_estep(h, X, dtype, utt_offsets, n_utts, n_frames, utt_model, models, out_stats,
+                            (hipStream_t)stream);
+        if (rc != SRX_EUNSUPPORTED) return rc;
+    }
     if (allow_fused && dtype == SRX_F32) {
         // small jobs first: one lane per utterance beats a matrix-core wave they cannot fill
         if (h->estep_path != SRX_ESTEP_FUSED) {

@@ -1096,6 +1096,7 @@ static int plan_fill(srx_mfcc_plan* p, const srx_mfcc_cfg_t* cfg) {
         }
         int nq = 1;
         for (const Blk& b : blk) nq = std::max(nq, quads(b));
+        nq = (nq + 3) & ~3;      // (the kernel keeps four quads' operands in flight and walks them by fours)
         const int kk = (((cfg->n_mel + 3) / 4) + 3) & ~3;      // filters per DCT split, a multiple of 4
         std::vector<float> w4((size_t)nq * 64 * 4, 0.f), dctA((size_t)64 * kk, 0.f);
         std::vector<int32_t> meta(48, 0);

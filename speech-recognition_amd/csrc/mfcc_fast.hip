@@ -73,22 +73,6 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Diagnostic build only (-DSRX_MFCC_STAMPS, never in libsrx.so proper): cycles a wave spends in
-// each phase of a step, summed over all waves into g_stamps[phase] (and the number of steps into
-// g_stamps[15]); srx_debug_mfcc_stamps copies the sums to the host and clears them.  The stamps
-// go to this array only; no output value depends on them.
-#ifdef SRX_MFCC_STAMPS
-__device__ unsigned long long g_stamps[16];
-#define STAMP(i)                                                   \
-    do {                                                           \
-        const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
-        st_acc[i] += now__ - st_last;                              \
-        st_last = now__;                                           \
-    } while (0)
-#else
-#define STAMP(i) do {} while (0)
-#endif
-
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 constexpr int brev(int i, int bits) {
     int r = 0;
@@ -358,11 +342,6 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
     const int64_t b_begin = (int64_t)blockIdx.x * per_block;
     const int64_t b_end = b_begin + per_block < n_chunks ? b_begin + per_block : n_chunks;
     if (b_begin >= b_end) return;
-#ifdef SRX_MFCC_STAMPS
-    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long st_last = __builtin_amdgcn_s_memtime();
-    unsigned long long st_steps = 0;
-#endif
     const unsigned hop = (unsigned)c.hop;
     // start sample of this lane group's row in step bq (-1: none)
     auto row_of = [&](int64_t bq) { return bq * FB + item; };
@@ -402,10 +381,6 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
     // into the same registers right there, a whole step before they are used)
     auto transform = [&](int start, int64_t row, float (&xc)[2 * P], int next_start, int64_t next_b) {
         const bool have = start >= 0;
-        STAMP(0);
-#ifdef SRX_MFCC_STAMPS
-        ++st_steps;
-#endif
         // ---- 1. window, bit-reversed register order, P-point FFT over n1
         const bool any = __ballot(have) != 0;     // no frame starts in this chunk for this wave?
         cpx z1[P];
@@ -418,7 +393,6 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
         fetch(next_start, next_b, xc);
         if (any) {
         fft_regs<P>(z1);
-        STAMP(1);
         // ---- 2. twiddle W_H^(j k1) and 3. transpose through LDS: Y[k1][j]
 #pragma unroll
         for (int k1 = 0; k1 < P; ++k1) Y[k1 * 17 + j] = twiddled(s_tw2[k1 * 16 + j], z1[k1], k1 == 0);
@@ -434,10 +408,8 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
             }
         }
         wave_sync();
-        STAMP(2);
 #pragma unroll
         for (int i = 0; i < KB; ++i) fft_regs<16>(z2[i]);
-        STAMP(3);
         // ---- 4. real-input spectrum, power / N.  Bins k and H-k share their inputs.  Lane j now
         // holds Z[j + 16 m], m < P (m = KB k2 + i).  Its bins k = j + 16 mm, mm < P/2, are its
         // own lower half; their partners H - k = (16 - j) + 16 (P - 1 - mm) are the UPPER half of
@@ -482,7 +454,6 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
         }
         if (j < 3) pw[H + 1 + j] = 0.f;           // padding that meets zero weights: keep it finite
         wave_sync();
-        STAMP(4);
         // ---- 5. mel energies: block `blk` adds its range of bins for 4 filters x 4 frames
         {
             // four accumulators, one per bin of a quad: a 4x4x1 product waits for the one before
@@ -493,38 +464,44 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
             for (int e = 0; e < 4; ++e) ac[e] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float* wq = s_w4 + lane * 4;
             const float* pq = pw_col + k0;
-            // (the next quad's operands are requested before this quad's products; two quads
-            // per trip with two operand sets, so that no set is copied into the other)
-            f32x4 wa = *(const f32x4*)wq, pa = *(const f32x4*)pq, wb, pb;
+            // (Four quads' operands are in flight at any time: an LDS read takes a few hundred
+            // cycles to come back while twelve waves queue theirs, a quad's four products 32.
+            // nq is a multiple of 4; the refills past the last quad repeat it and are not used.)
+            f32x4 wa[4], pa[4];
             const int nq = c.nq;
-            int q = 0;
-            for (; q + 2 <= nq; q += 2) {
-                wb = *(const f32x4*)(wq + (q + 1) * 256);
-                pb = *(const f32x4*)(pq + (q + 1) * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ac[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[e], pa[e], ac[e], 0, 0, 0);
-                const int q2 = q + 2 < nq ? q + 2 : q + 1;
-                wa = *(const f32x4*)(wq + q2 * 256);
-                pa = *(const f32x4*)(pq + q2 * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ac[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[e], pb[e], ac[e], 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+                wa[u] = *(const f32x4*)(wq + u * 256);
+                pa[u] = *(const f32x4*)(pq + u * 4);
             }
-            if (q < nq) {
+            for (int q = 0; q < nq; q += 4) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ac[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[e], pa[e], ac[e], 0, 0, 0);
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        ac[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[u][e], pa[u][e], ac[e], 0, 0, 0);
+                    const int qn = q + 4 + u < nq ? q + 4 + u : nq - 1;
+                    wa[u] = *(const f32x4*)(wq + qn * 256);
+                    pa[u] = *(const f32x4*)(pq + qn * 4);
+                }
             }
             const f32x4 acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
             *(f32x4*)part_at(blk, col) = acc;
         }
         wave_sync();
-        STAMP(5);
         // blocks of one group of filters add up; exact zeros -> eps; log_mult * log10
         // log_mult * log10(2) as a float and the part of it the float misses
         const double scale_d = (double)c.log_mult * 0.30102999566398120;
         const float log2_scale = (float)scale_d, log2_scale_lo = (float)(scale_d - (double)log2_scale);
         if (blk < c.groups) {
+            // (a group's blocks are read at once, not one after the other's answer)
             f32x4 e = {0.f, 0.f, 0.f, 0.f};
-            for (int nb = grp_first; nb < grp_first + grp_cnt; ++nb) e += *(const f32x4*)part_at(nb, col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v = *(const f32x4*)part_at(grp_first + (i < grp_cnt ? i : grp_cnt - 1), col);
+                e += i < grp_cnt ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            for (int nb = grp_first + 4; nb < grp_first + grp_cnt; ++nb) e += *(const f32x4*)part_at(nb, col);
             f32x4 l;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -540,7 +517,6 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
             *(f32x4*)(lm_col + 4 * blk) = f32x4{0.f, 0.f, 0.f, 0.f};      // padding of the log-mel row
         }
         wave_sync();
-        STAMP(6);
         // ---- DCT-II rows: 4 cepstra x 4 frames per block, over one slice of the filters
         {
             f32x4 ac[4];
@@ -548,18 +524,29 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
             for (int e = 0; e < 4; ++e) ac[e] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float* aq = s_dctA + lane * c.kk;
             const float* bq = lm_col + ks * c.kk;
-            // (kk is a multiple of 4 and at most 32: two quads' operands are requested at once)
+            // (kk is a multiple of 4 and at most 32; up to four quads' operands in flight)
             const int kk = c.kk;
+            f32x4 da[4], db[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int qn = 4 * u < kk ? 4 * u : kk - 4;
+                da[u] = *(const f32x4*)(aq + qn);
+                db[u] = *(const f32x4*)(bq + qn);
+            }
 #pragma unroll 1
-            for (int q = 0; q < kk; q += 8) {
-                const f32x4 a0 = *(const f32x4*)(aq + q), b0 = *(const f32x4*)(bq + q);
-                const int q1 = q + 4 < kk ? q + 4 : q;
-                const f32x4 a1 = *(const f32x4*)(aq + q1), b1 = *(const f32x4*)(bq + q1);
+            for (int q = 0; q < kk; q += 16) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ac[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[e], b0[e], ac[e], 0, 0, 0);
-                if (q + 4 < kk) {
+                for (int u = 0; u < 4; ++u) {
+                    if (q + 4 * u < kk) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ac[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[e], b1[e], ac[e], 0, 0, 0);
+                        for (int e = 0; e < 4; ++e)
+                            ac[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(da[u][e], db[u][e], ac[e], 0, 0, 0);
+                    }
+                    const int qn = q + 16 + 4 * u < kk ? q + 16 + 4 * u : kk - 4;
+                    if (q + 16 < kk) {
+                        da[u] = *(const f32x4*)(aq + qn);
+                        db[u] = *(const f32x4*)(bq + qn);
+                    }
                 }
             }
             f32x4 acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
@@ -578,7 +565,6 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
             }
         }
         wave_sync();
-        STAMP(7);
         }   // any
     };
     float x[2 * P];
@@ -590,12 +576,6 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
         s0 = s1;
         s1 = s2;
     }
-#ifdef SRX_MFCC_STAMPS
-    if (lane == 0) {
-        for (int i = 0; i < 10; ++i) atomicAdd(&g_stamps[i], st_acc[i]);
-        atomicAdd(&g_stamps[15], st_steps);
-    }
-#endif
 }
 
 template <int P>
@@ -639,15 +619,6 @@ int launch_fast(srx_context* h, const float* audio, const int64_t* so, int64_t U
 
 }  // namespace
 
-#ifdef SRX_MFCC_STAMPS
-extern "C" int srx_debug_mfcc_stamps(unsigned long long* out16) {
-    SRX_HIP(hipDeviceSynchronize());
-    SRX_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16));
-    unsigned long long zero[16] = {};
-    SRX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof(zero)));
-    return SRX_OK;
-}
-#endif
 
 int srx_mfcc_fast_cepstra(srx_context* h, srx_mfcc_plan* p, const float* audio, const int64_t* so,
                           int64_t U, int64_t total, float* cep, hipStream_t st) {

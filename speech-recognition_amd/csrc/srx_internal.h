@@ -115,6 +115,11 @@ int srx_generic_mstep(srx_context* h, const double* stats, const srx_priors_t* p
 int srx_lane_estep(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
                    const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* md,
                    double* out_stats, hipStream_t st);
+// E-step of the smallest jobs (at most 2048 utterances, at most 4 states, either dtype): one
+// wave per utterance, the recursions cut into 64 pieces joined by a scan of transfer-matrix
+// products (estep_wave.hip); SRX_EUNSUPPORTED for every other job.
+int srx_wave_estep(srx_context* h, const void* X, int dtype, const int64_t* off, int64_t U, int64_t n_frames,
+                   const int32_t* utt_model, const srx_models_t* md, double* out_stats, hipStream_t st);
 // The same for float64 data (b~ of every frame exponentiated in a pass of its own).
 int srx_lane_estep_f64(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
                        const int32_t* utt_model, const int64_t* utt_order, const srx_models_t* md,

@@ -71,9 +71,11 @@ class Context:
         check(lib.srx_set_option(self._h, _lib.SRX_OPT_EXACT_F32, int(bool(on))), "srx_set_option")
 
     def set_estep_path(self, path):
-        """Kernels of the float32 E-step: "auto" (one lane per utterance for small jobs of at
-        most 8 states, the fused matrix-core kernel otherwise), "fused" or "lane"."""
-        code = {"auto": _lib.SRX_ESTEP_AUTO, "fused": _lib.SRX_ESTEP_FUSED, "lane": _lib.SRX_ESTEP_LANE}[path]
+        """Kernels of the E-step: "auto" (one wave per utterance for the smallest jobs -- at most
+        2048 utterances and 4 states, either dtype --, one lane per utterance for small jobs of
+        at most 8 states, the fused matrix-core kernel otherwise), "fused", "lane" or "wave"."""
+        code = {"auto": _lib.SRX_ESTEP_AUTO, "fused": _lib.SRX_ESTEP_FUSED, "lane": _lib.SRX_ESTEP_LANE,
+                "wave": _lib.SRX_ESTEP_WAVE}[path]
         check(lib.srx_set_option(self._h, _lib.SRX_OPT_ESTEP_PATH, code), "srx_set_option")
 
     def set_viterbi_path(self, path):

@@ -1039,6 +1039,76 @@ def test_small_job_estep_paths_agree_with_oracle(sra, ctx, M, S, D):
         assert np.abs(res[dtype, "lane"] - res[dtype, "fused"]).max() <= 2 * tol * scale
 
 
+@pytest.mark.parametrize("M,S,D,tmax", [(1, 1, 1, 90), (6, 3, 26, 240), (5, 2, 9, 700), (4, 4, 39, 130),
+                                        (2, 3, 100, 64)])
+def test_wave_per_utterance_estep_against_oracle(sra, ctx, M, S, D, tmax):
+    """The E-step of the smallest jobs (one wave per utterance, recursions cut into 64 pieces
+    joined by scans of transfer-matrix products; what "auto" picks for at most 2048 utterances of
+    models with at most 4 states): ragged batches with empty, one- and two-frame utterances,
+    utterances shorter and much longer than 64 frames, a model without utterances, a left-to-right
+    model with structural zeros, both dtypes; statistics against the oracle, the
+    transitions-only selection against the full one, and the same call twice bit for bit."""
+    rng = np.random.default_rng(77 * M + 10 * S + D)
+    prms = [ho.random_params(rng, S, D) for _ in range(M)]
+    if S >= 3:                                        # structural zeros: left to right, start in state 0
+        A = np.triu(prms[0].A) + 1e-300
+        A = np.triu(A / A.sum(axis=1, keepdims=True))
+        pi = np.zeros(S); pi[0] = 1.0
+        prms[0] = ho.Params(pi, A / A.sum(axis=1, keepdims=True), prms[0].means, prms[0].covars)
+    U = 70
+    lengths = rng.integers(1, tmax, size=U)
+    lengths[[3, 64]] = 0
+    lengths[[5, 69]] = 1
+    lengths[7] = 2
+    lengths[9], lengths[10], lengths[11] = 63, 64, 65
+    um = rng.integers(0, M, size=U).astype(np.int32)
+    if M > 2:
+        um[um == 1] = 0
+    X = rng.standard_normal((int(lengths.sum()), D))
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    if S >= 3:
+        # the left-to-right model's utterances are drawn from it (frames far from every state
+        # the chain can be in have no float32 density at all: the dtype's range, not the kernel's)
+        for u in np.flatnonzero(um == 0):
+            st = 0
+            for t in range(off[u], off[u + 1]):
+                X[t] = prms[0].means[st] + rng.standard_normal(D) * np.sqrt(prms[0].covars[st])
+                st = rng.choice(S, p=prms[0].A[st])
+    bank = _bank(sra, ctx, prms)
+    umd = ctx.tensor(um)
+    for dtype, tol in (("float32", 2e-5), ("float64", 1e-9)):
+        data = sra.Ragged(ctx, X, lengths, dtype=dtype)
+        ctx.set_estep_path("wave")
+        try:
+            raw = bank.estep(data, umd).cpu().numpy()
+            raw2 = bank.estep(data, umd).cpu().numpy()
+            part = bank.estep(data, umd, stats="transitions").cpu().numpy()
+        finally:
+            ctx.set_estep_path("auto")
+        auto = bank.estep(data, umd).cpu().numpy()
+        assert np.array_equal(raw, raw2) and np.array_equal(raw, auto)      # "auto" takes this path here
+        got, gp = bank.unpack_stats(ctx.tensor(raw)), bank.unpack_stats(ctx.tensor(part))
+        for m in range(M):
+            sel = [u for u in range(U) if um[u] == m and lengths[u] > 0]
+            if not sel:
+                assert got[m]["nobs"] == 0 and got[m]["logprob"] == 0.0 and not got[m]["obs"].any()
+                continue
+            Xm = np.vstack([X[off[u]:off[u + 1]] for u in sel])
+            st, lps = ho.estep(prms[m], Xm, [int(lengths[u]) for u in sel], loops=False)
+            lp = float(np.sum(lps))
+            assert got[m]["nobs"] == len(sel)
+            assert abs(got[m]["logprob"] - lp) <= tol * abs(lp)
+            for k in ("start", "trans", "post", "obs", "obs**2"):
+                np.testing.assert_allclose(got[m][k], st[k], rtol=tol, atol=tol * max(1.0, np.abs(st[k]).max()),
+                                           err_msg=f"{dtype} model {m} {k}")
+            assert gp[m]["logprob"] == got[m]["logprob"] and gp[m]["nobs"] == got[m]["nobs"]
+            assert np.array_equal(gp[m]["trans"], got[m]["trans"]) and np.array_equal(gp[m]["start"], got[m]["start"])
+            assert not gp[m]["obs"].any() and not gp[m]["post"].any()
+    # structural zeros of the transition matrix stay exact zeros in the xi sums
+    if S >= 3:
+        assert np.all(got[0]["trans"][np.tril_indices(S, -1)] == 0.0)
+
+
 def test_scoring_with_a_length_order_is_bit_identical(sra, ctx):
     """Ragged float32 batches are scored through srx_forward_score_ordered (utterances of
     similar length share a wave): bit for bit the scores of srx_forward_score, which takes
