@@ -1083,20 +1083,33 @@ static int plan_fill(srx_mfcc_plan* p, const srx_mfcc_cfg_t* cfg) {
             blk.push_back({g, lo & ~3, hi});
         }
         auto quads = [](const Blk& b) { return (b.hi - b.lo + 3) / 4; };
-        while (blk.size() < 16) {
-            size_t best = 0;
-            for (size_t i = 1; i < blk.size(); ++i)
-                if (quads(blk[i]) > quads(blk[best])) best = i;
-            const int q = quads(blk[best]);
-            if (q <= 1) break;
-            const int mid = blk[best].lo + 4 * (q / 2);
-            Blk tail{blk[best].g, mid, blk[best].hi};
-            blk[best].hi = mid;
-            blk.insert(blk.begin() + best + 1, tail);
-        }
+        // The kernel walks nq quads in every block, so nq is what the stage costs: take the
+        // smallest piece length that cuts the groups' ranges into at most 16 pieces, among the
+        // lengths the kernel can walk (multiples of 3 or 4: it keeps that many quads' operands
+        // in flight), and cut every group into equal pieces of at most that length.
         int nq = 1;
         for (const Blk& b : blk) nq = std::max(nq, quads(b));
-        nq = (nq + 3) & ~3;      // (the kernel keeps four quads' operands in flight and walks them by fours)
+        for (int cand = 3; cand <= nq; ++cand) {
+            if (cand % 3 != 0 && cand % 4 != 0) continue;
+            int pieces = 0;
+            for (const Blk& b : blk) pieces += std::max(1, (quads(b) + cand - 1) / cand);
+            if (pieces <= 16) {
+                nq = cand;
+                break;
+            }
+        }
+        while (nq % 3 != 0 && nq % 4 != 0) ++nq;
+        {
+            std::vector<Blk> cut;
+            for (const Blk& b : blk) {
+                const int q = quads(b), n = std::max(1, (q + nq - 1) / nq);
+                for (int i = 0; i < n; ++i) {
+                    const int q0 = q * i / n, q1 = q * (i + 1) / n;      // (pieces of q / n quads, at most nq)
+                    cut.push_back({b.g, b.lo + 4 * q0, i + 1 == n ? b.hi : b.lo + 4 * q1});
+                }
+            }
+            if (cut.size() <= 16) blk = cut;
+        }
         const int kk = (((cfg->n_mel + 3) / 4) + 3) & ~3;      // filters per DCT split, a multiple of 4
         std::vector<float> w4((size_t)nq * 64 * 4, 0.f), dctA((size_t)64 * kk, 0.f);
         std::vector<int32_t> meta(48, 0);

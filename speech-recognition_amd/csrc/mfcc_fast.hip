@@ -29,6 +29,8 @@
 
 #include <math.h>
 
+#include <type_traits>
+
 namespace {
 
 constexpr int kWave = 64;
@@ -464,27 +466,33 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
             for (int e = 0; e < 4; ++e) ac[e] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float* wq = s_w4 + lane * 4;
             const float* pq = pw_col + k0;
-            // (Four quads' operands are in flight at any time: an LDS read takes a few hundred
-            // cycles to come back while twelve waves queue theirs, a quad's four products 32.
-            // nq is a multiple of 4; the refills past the last quad repeat it and are not used.)
-            f32x4 wa[4], pa[4];
+            // (Three or four quads' operands are in flight at any time: an LDS read takes a few
+            // hundred cycles to come back while twelve waves queue theirs, a quad's four products
+            // a few dozen.  nq is a multiple of 3 or of 4; the refills past the last quad repeat it
+            // and are not used.)
             const int nq = c.nq;
+            auto walk = [&](auto depth) {
+                constexpr int DEPTH = decltype(depth)::value;
+                f32x4 wa[DEPTH], pa[DEPTH];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                wa[u] = *(const f32x4*)(wq + u * 256);
-                pa[u] = *(const f32x4*)(pq + u * 4);
-            }
-            for (int q = 0; q < nq; q += 4) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        ac[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[u][e], pa[u][e], ac[e], 0, 0, 0);
-                    const int qn = q + 4 + u < nq ? q + 4 + u : nq - 1;
-                    wa[u] = *(const f32x4*)(wq + qn * 256);
-                    pa[u] = *(const f32x4*)(pq + qn * 4);
+                for (int u = 0; u < DEPTH; ++u) {
+                    wa[u] = *(const f32x4*)(wq + u * 256);
+                    pa[u] = *(const f32x4*)(pq + u * 4);
                 }
-            }
+                for (int q = 0; q < nq; q += DEPTH) {
+#pragma unroll
+                    for (int u = 0; u < DEPTH; ++u) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            ac[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[u][e], pa[u][e], ac[e], 0, 0, 0);
+                        const int qn = q + DEPTH + u < nq ? q + DEPTH + u : nq - 1;
+                        wa[u] = *(const f32x4*)(wq + qn * 256);
+                        pa[u] = *(const f32x4*)(pq + qn * 4);
+                    }
+                }
+            };
+            if (nq % 4 == 0) walk(std::integral_constant<int, 4>{});
+            else walk(std::integral_constant<int, 3>{});
             const f32x4 acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
             *(f32x4*)part_at(blk, col) = acc;
         }
