@@ -36,6 +36,18 @@ def _signals(seed, lengths):
 LENGTHS = [20727, 13230, 512 * 20, 512 * 20 - 1, 2048, 1500, 1, 0, 52920]
 
 
+def _row_rms_error(got, ref):
+    """Largest |got - ref| of each cepstral coefficient in units of that coefficient's RMS over
+    the utterance (the measure of the reference front-end's tests; a coefficient that is zero
+    throughout is measured against the largest RMS; an utterance of fewer than 8 frames, where
+    a coefficient's RMS can be next to nothing by chance, against its largest cepstrum)."""
+    if ref.shape[0] < 8:
+        return float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+    rms = np.sqrt(np.mean(np.square(ref), axis=0))
+    rms = np.where(rms > 0, rms, max(float(rms.max()), 1e-300))
+    return float(np.max(np.abs(got - ref) / rms))
+
+
 @pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 1e-4)])
 @pytest.mark.parametrize("pad_mode", ["constant", "reflect"])
 def test_librosa_mfcc_matches_oracle(sra, dtype, tol, pad_mode):
@@ -47,12 +59,15 @@ def test_librosa_mfcc_matches_oracle(sra, dtype, tol, pad_mode):
     f, lens = sra.mfcc.librosa_mfcc_batch(sigs, 22050, 13, dtype=dtype, pad_mode=pad_mode)
     assert list(lens) == [cfg.n_frames(n) for n in lengths]
     off = np.concatenate([[0], np.cumsum(lens)])
+    worst = 0.0
     for k, s in enumerate(sigs):
         ref = mo.librosa_mfcc(s, cfg)
         got = f[off[k]:off[k + 1]]
         assert got.shape == ref.shape
         if ref.size:
-            assert np.max(np.abs(got - ref)) <= tol * np.max(np.abs(ref)), (k, lengths[k])
+            worst = max(worst, _row_rms_error(got, ref))
+    print(f"librosa conventions {dtype} {pad_mode}: largest error / coefficient RMS {worst:.2e}")
+    assert worst <= tol
 
 
 @pytest.mark.parametrize("dtype,tol", [("float64", 1e-8), ("float32", 2e-3)])
@@ -71,7 +86,7 @@ def test_librosa_extract_zscored_and_other_shapes(sra, dtype, tol):
     off2 = np.concatenate([[0], np.cumsum(lens2)])
     for k, s in enumerate(sigs):
         ref = mo.librosa_mfcc(s, cfg2)
-        assert np.max(np.abs(f2[off2[k]:off2[k + 1]] - ref)) <= tol * 1e-1 * np.max(np.abs(ref))
+        assert _row_rms_error(f2[off2[k]:off2[k + 1]], ref) <= tol * 1e-1
 
 
 def test_hmm_lib_harness_end_to_end(sra, tmp_path):

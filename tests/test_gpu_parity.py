@@ -414,16 +414,27 @@ def test_cross_validate_batched_matches_reference(sra, ctx, folds_golden, dtype)
                                         init_fn=fold_init, dtype=dtype, ctx=ctx)
     sp, A, mu, cv = res["bank"].params_host()
     tight = dtype == "float64"
+    worst = {"mu": 0.0, "A": 0.0, "hist": 0.0, "scores": 0.0}
+    for k in range(1, 6):
+        for w_i, w in enumerate(words):
+            q, m = f"f{k}_{w}_", (k - 1) * len(words) + w_i
+            worst["mu"] = max(worst["mu"], float(np.max(np.abs(mu[m] - g[q + "mu"]) / (np.abs(g[q + "mu"]) + 0.1))))
+            worst["A"] = max(worst["A"], float(np.max(np.abs(A[m] - g[q + "A"]) / (np.abs(g[q + "A"]) + 1e-2))))
+            worst["hist"] = max(worst["hist"], float(np.max(np.abs(res["hist"][k - 1, w_i] / g[q + "hist"] - 1))))
+        worst["scores"] = max(worst["scores"], float(np.max(np.abs(res["folds"][k - 1]["scores"] / g[f"f{k}_scores"] - 1))))
+    print(f"cross_validate {dtype}: largest deviations after {int(g['n_iter'])} EM iterations", worst)
     for k in range(1, 6):
         fr = res["folds"][k - 1]
         assert fr["pred"] == list(g[f"f{k}_pred"])
         assert fr["right"] == int(g[f"f{k}_right"])
-        np.testing.assert_allclose(fr["scores"], g[f"f{k}_scores"], rtol=1e-7 if tight else 2e-4)
+        # (measured on MI355X after 8 EM iterations: float64 1e-15 scores, 6e-14 means; float32
+        # 2.2e-6 scores, 1.4e-7 histories, 1.1e-5 of |mean| + 0.1, 3.2e-6 of |a_ij| + 0.01)
+        np.testing.assert_allclose(fr["scores"], g[f"f{k}_scores"], rtol=1e-12 if tight else 2e-5)
         for w_i, w in enumerate(words):
             q, m = f"f{k}_{w}_", (k - 1) * len(words) + w_i
-            np.testing.assert_allclose(res["hist"][k - 1, w_i], g[q + "hist"], rtol=1e-9 if tight else 1e-5)
-            np.testing.assert_allclose(mu[m], g[q + "mu"], rtol=1e-5 if tight else 1e-3, atol=1e-7 if tight else 1e-4)
-            np.testing.assert_allclose(A[m], g[q + "A"], rtol=1e-5 if tight else 1e-3, atol=1e-9 if tight else 1e-5)
+            np.testing.assert_allclose(res["hist"][k - 1, w_i], g[q + "hist"], rtol=1e-12 if tight else 2e-6)
+            np.testing.assert_allclose(mu[m], g[q + "mu"], rtol=1e-10 if tight else 5e-5, atol=1e-11 if tight else 5e-6)
+            np.testing.assert_allclose(A[m], g[q + "A"], rtol=1e-10 if tight else 2e-5, atol=1e-12 if tight else 2e-7)
 
 
 @pytest.mark.parametrize("M,S,D", [(30, 3, 26), (12, 8, 39), (7, 8, 13), (13, 5, 39), (50, 4, 20),
