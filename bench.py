@@ -436,16 +436,18 @@ def main():
         reps = 3
         raw_frames = n_utt_fe * ((n_samp - 400) // 160 + 1)
         # The transform kernel executes about 16.6 kflop of float32 vector / 4x4 matrix work per
-        # frame (packed adds 5.1 k, packed multiplies and fused multiply-adds 4.8 k, window and
+        # frame (butterfly adds 5.1 k, multiplies and fused multiply-adds 4.8 k, window and
         # power 1.1 k, mel and DCT blocks 5.6 k): the 796 B/frame HBM line (1.0e10 frames/s) would
         # need 167 TFLOP/s of it, more than the 157.3 TFLOP/s vector peak -- this formulation is
-        # bound by vector-instruction issue, which is what "vector_peak_frac" measures.
+        # bound by vector-instruction issue, which is what "vector_peak_frac" measures (shader
+        # counters: profiles/r3_mfcc_sq_counters.txt).
         flop_per_frame = 16.6e3
         extra["mfcc"] = {"frames_per_s": raw_frames * world / dtf, "frames_per_gpu": raw_frames,
                          "ms": dtf * 1e3,
                          "hbm_frac": raw_frames * 796 / dtf / 1e9 / HBM_PEAK_GBS,
-                         "bound": "vector ALU issue (about 640 vector + 120 LDS + 44 matrix instructions per "
-                                  "wave-step of 4 frames); HBM line shown for reference",
+                         "bound": "vector ALU issue (832 vector + 112 LDS + 44 matrix instructions per wave-step of "
+                                  "4 frames; the three waves of a SIMD keep its vector pipe busy 0.93 of the kernel's "
+                                  "time by the shader counters); HBM line shown for reference",
                          "flop_per_frame_executed": flop_per_frame,
                          "vector_peak_frac": raw_frames * flop_per_frame / dtf / 157.3e12,
                          "config": "16 kHz, 400/160 samples, 512-pt FFT, 40 mel, 13 MFCC+d+dd, z-score"}
