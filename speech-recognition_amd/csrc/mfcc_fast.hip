@@ -491,7 +491,34 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
                     }
                 }
             };
-            if (nq % 4 == 0) walk(std::integral_constant<int, 4>{});
+            // The plans of the two shapes this kernel is built for walk 6 quads (16 kHz, 512
+            // points, 40 filters) and 12 (22.05 kHz, 1024 points, 26 filters): with the count
+            // known, every LDS address is the lane's base plus an immediate, the first product of
+            // each accumulator starts from a zero literal, and no refill is clamped.
+            auto walk_fixed = [&](auto count, auto depth) {
+                constexpr int NQ = decltype(count)::value, DEPTH = decltype(depth)::value;
+                f32x4 wa[DEPTH], pa[DEPTH];
+#pragma unroll
+                for (int u = 0; u < DEPTH; ++u) {
+                    wa[u] = *(const f32x4*)(wq + u * 256);
+                    pa[u] = *(const f32x4*)(pq + u * 4);
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int u = q % DEPTH;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        ac[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(
+                            wa[u][e], pa[u][e], q == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : ac[e], 0, 0, 0);
+                    if (q + DEPTH < NQ) {
+                        wa[u] = *(const f32x4*)(wq + (q + DEPTH) * 256);
+                        pa[u] = *(const f32x4*)(pq + (q + DEPTH) * 4);
+                    }
+                }
+            };
+            if (nq == 6) walk_fixed(std::integral_constant<int, 6>{}, std::integral_constant<int, 3>{});
+            else if (nq == 12) walk_fixed(std::integral_constant<int, 12>{}, std::integral_constant<int, 4>{});
+            else if (nq % 4 == 0) walk(std::integral_constant<int, 4>{});
             else walk(std::integral_constant<int, 3>{});
             const f32x4 acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
             *(f32x4*)part_at(blk, col) = acc;
@@ -534,6 +561,26 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
             const float* bq = lm_col + ks * c.kk;
             // (kk is a multiple of 4 and at most 32; up to four quads' operands in flight)
             const int kk = c.kk;
+            // (the two shapes' plans: 12 filters per slice of 40, 8 per slice of 26 -- all operands
+            // read at once from immediate offsets, accumulators started from a zero literal)
+            auto dct_fixed = [&](auto count) {
+                constexpr int KQ = decltype(count)::value;      // quads of filters
+                f32x4 da[KQ], db[KQ];
+#pragma unroll
+                for (int u = 0; u < KQ; ++u) {
+                    da[u] = *(const f32x4*)(aq + 4 * u);
+                    db[u] = *(const f32x4*)(bq + 4 * u);
+                }
+#pragma unroll
+                for (int u = 0; u < KQ; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        ac[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(
+                            da[u][e], db[u][e], u == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : ac[e], 0, 0, 0);
+            };
+            if (kk == 12) dct_fixed(std::integral_constant<int, 3>{});
+            else if (kk == 8) dct_fixed(std::integral_constant<int, 2>{});
+            else {
             f32x4 da[4], db[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -556,6 +603,7 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
                         db[u] = *(const f32x4*)(bq + qn);
                     }
                 }
+            }
             }
             f32x4 acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
 #pragma unroll
