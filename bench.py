@@ -684,6 +684,11 @@ def main():
                                "config": "6 models x 16 states x 39 dims, full M-step, one all-reduce of "
                                          f"{tr.stats.numel()} float64 per iteration",
                                "allreduce_ms": ar_ms, "rccl_ranks": ranks_seen,
+                               # the E-step kernel reads X twice and writes and reads its float32
+                               # lattice: 446 B/frame by the counters (profiles/traffic_secondary.json),
+                               # against 156 B/frame of features; per GPU
+                               "hbm_frac_algorithmic": Ut * T_FRAMES * 156.0 / dtt / 1e9 / HBM_PEAK_GBS,
+                               "hbm_frac_measured_traffic": Ut * T_FRAMES * 446.0 / dtt / 1e9 / HBM_PEAK_GBS,
                                "logprob_model0": float(lp[0].item()),
                                "transitions_only_iter_per_s": 1.0 / dt3,
                                "transitions_only_ms_per_iter": dt3 * 1e3}
