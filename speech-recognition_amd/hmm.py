@@ -404,8 +404,8 @@ class MyGaussianHMM:
         # _GRAPH_AFTER iterations captures it once per parity (two pinned slots, two snapshots)
         # as a HIP graph and replays those: one host call per iteration instead of a dozen.
         # (use_graph=True.  Off by default: at the reference's own job size the iteration is
-        # bound by the GPU's chain of dependent kernels, 0.106 ms launch by launch and 0.109 ms
-        # replayed, so the host calls were never what it waited for.)
+        # bound by the GPU's chain of dependent kernels -- 0.059 ms launch by launch and 0.067 ms
+        # replayed on 150 utterances -- so the host calls were never what it waited for.)
         n_iter = int(self.n_iter)
         ctx = bank.ctx
         slots = torch.full((2,), float("nan"), dtype=torch.float64).pin_memory()

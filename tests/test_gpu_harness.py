@@ -255,3 +255,25 @@ def test_fit_from_device_features_equals_fit_from_host_features(sra, hg):
     assert st["nobs"] == 1 and np.array_equal(st["trans"], one["trans"])
     np.testing.assert_allclose(a.compute_likelihood(x0), np.exp(a.compute_log_likelihood(x0)))
     assert a.score_log(x0, compute_posteriors=False)[0] == a.score_scaling(x0, compute_posteriors=False)[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_fit_with_graph_replay_equals_launch_by_launch(sra, dtype):
+    """use_graph=True replays the EM iteration as two captured graphs from the seventh iteration
+    on: same kernels in the same order, so history and parameters are the same bits."""
+    rng = np.random.default_rng(21)
+    lengths = rng.integers(40, 120, size=30)
+    z = rng.standard_normal((int(lengths.sum()), 13))
+    fits = []
+    for use_graph in (False, True):
+        m = sra.MyGaussianHMM(n_components=3, n_iter=25, tol=-np.inf, verbose=False, random_state=5,
+                              dtype=dtype, mstep="full", use_graph=use_graph)
+        np.random.seed(17)
+        m.fit(z, lengths)
+        fits.append(m)
+    a, b = fits
+    assert a.monitor_.iter == b.monitor_.iter == 25
+    assert list(a.monitor_.history) == list(b.monitor_.history)
+    for name in ("startprob_", "transmat_", "means_", "_covars_"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
