@@ -9,8 +9,9 @@
 // normalised to sum 1 (hmm.py:325-328; utils.py:201-218 sums terms that add up to 1 per
 // transition) -- so the work splits: lane k owns the frames [k C, (k+1) C), C = ceil(T / 64):
 //   1. emission: log-densities of its frames (hmm.py:154-163, direct form), b~ = exp(l - max l);
-//   2. its piece's product P_k = F_t ... F_t' (renormalised by its largest entry at every
-//      factor, the scale is of no consequence);
+//   2. its piece's product P_k = F_t ... F_t' (every row renormalised with a binary exponent
+//      of its own at every factor, see Mat; the scale of a row is of no consequence in itself,
+//      the scales of the rows relative to each other are);
 //   3. an inclusive prefix scan and a suffix scan of the P_k over the 64 lanes (6 steps each,
 //      matrices passed by lane shuffles): what comes into the piece from the left as a
 //      forward vector, what comes in from the right as a backward vector;
@@ -40,11 +41,18 @@ template <> struct Ops<float> {
     static __device__ __forceinline__ float exp(float x) { return __expf(x); }
     static __device__ __forceinline__ float log(float x) { return __logf(x); }
     static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+    // x = m 2^e with m in [0.5, 1)
+    static __device__ __forceinline__ int expo(float x) { return __builtin_amdgcn_frexp_expf(x); }
+    static __device__ __forceinline__ float scale(float x, int n) { return ldexpf(x, n); }
+    static __device__ __forceinline__ float finite(float x) { return fminf(x, 3.4028234664e38f); }
 };
 template <> struct Ops<double> {
     static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
     static __device__ __forceinline__ double log(double x) { return ::log(x); }
     static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ int expo(double x) { return __builtin_amdgcn_frexp_exp(x); }
+    static __device__ __forceinline__ double scale(double x, int n) { return ldexp(x, n); }
+    static __device__ __forceinline__ double finite(double x) { return fmin(x, 1.7976931348623157e308); }
 };
 
 __device__ __forceinline__ void wave_mem_sync() {
@@ -55,37 +63,64 @@ __device__ __forceinline__ void wave_mem_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// A transfer matrix with ONE BINARY EXPONENT PER ROW: entry (i, j) = v[i][j] 2^e[i], the largest
+// v of a row in [0.5, 1) (kNone for a row of zeros).  Row i of a product of F_t is the
+// likelihood of the piece's frames from start state i; between start states that the model
+// does not really offer (a structural zero of A, a state the past has ruled out) and the one it
+// does, that likelihood differs by e^50 per frame at 39 features -- far more than one exponent
+// for the whole matrix could hold in the data's dtype, and the row that matters may be the small
+// one.  With its own exponent no row is ever lost to another; inside a row, terms that fall
+// below the dtype's range relative to the row's largest are the ones the sequential recursion
+// loses too.
+constexpr int kNone = -(1 << 28);
 template <typename R, int S>
 struct Mat {
     R v[S][S];
+    int e[S];
 };
 
+// row i to its largest entry in [0.5, 1), exponent adjusted
 template <typename R, int S>
-__device__ __forceinline__ void renorm(Mat<R, S>& m) {
+__device__ __forceinline__ void renorm_row(Mat<R, S>& m, int i, int base) {
     R mx = 0;
 #pragma unroll
-    for (int i = 0; i < S; ++i)
+    for (int j = 0; j < S; ++j) mx = m.v[i][j] > mx ? m.v[i][j] : mx;
+    const int ex = mx > 0 ? Ops<R>::expo(mx) : 0;
 #pragma unroll
-        for (int j = 0; j < S; ++j) mx = m.v[i][j] > mx ? m.v[i][j] : mx;
-    const R s = mx > 0 ? Ops<R>::rcp(mx) : (R)1;
-#pragma unroll
-    for (int i = 0; i < S; ++i)
-#pragma unroll
-        for (int j = 0; j < S; ++j) m.v[i][j] *= s;
+    for (int j = 0; j < S; ++j) m.v[i][j] = Ops<R>::scale(m.v[i][j], -ex);
+    m.e[i] = mx > 0 ? base + ex : kNone;
 }
 
 template <typename R, int S>
 __device__ __forceinline__ Mat<R, S> matmul(const Mat<R, S>& a, const Mat<R, S>& b) {
     Mat<R, S> c;
 #pragma unroll
-    for (int i = 0; i < S; ++i)
+    for (int i = 0; i < S; ++i) {
+        // term k of row i is a.v[i][k] 2^(a.e[i] + b.e[k]) b.v[k][:]: bring the terms to the
+        // largest of their exponents
+        int ek[S], er = kNone;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            ek[k] = a.v[i][k] > 0 && b.e[k] != kNone ? b.e[k] + Ops<R>::expo(a.v[i][k]) : kNone;
+            er = ek[k] > er ? ek[k] : er;
+        }
+        R w[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            int sh = b.e[k] - er + 1;                 // (a.v <= 1: the largest term stays below 2)
+            sh = sh < -4096 ? -4096 : sh;
+            w[k] = ek[k] != kNone ? Ops<R>::scale(a.v[i][k], sh) : (R)0;
+        }
 #pragma unroll
         for (int j = 0; j < S; ++j) {
             R acc = 0;
 #pragma unroll
-            for (int l = 0; l < S; ++l) acc += a.v[i][l] * b.v[l][j];
+            for (int k = 0; k < S; ++k) acc += w[k] * b.v[k][j];
             c.v[i][j] = acc;
         }
+        renorm_row(c, i, a.e[i] == kNone || er == kNone ? kNone : a.e[i] + er - 1);
+        if (a.e[i] == kNone || er == kNone) c.e[i] = kNone;
+    }
     return c;
 }
 
@@ -93,9 +128,11 @@ template <typename R, int S>
 __device__ __forceinline__ Mat<R, S> shfl_mat(const Mat<R, S>& m, int src_lane) {
     Mat<R, S> o;
 #pragma unroll
-    for (int i = 0; i < S; ++i)
+    for (int i = 0; i < S; ++i) {
+        o.e[i] = __shfl(m.e[i], src_lane, 64);
 #pragma unroll
         for (int j = 0; j < S; ++j) o.v[i][j] = __shfl(m.v[i][j], src_lane, 64);
+    }
     return o;
 }
 
@@ -167,11 +204,13 @@ __global__ __launch_bounds__(64) void estep_wave_kernel(
     auto mx_at = [&](int t) { return fr + (size_t)t * kFrameWords<S> + 3 * S; };     // row maximum
 
     // ---- 1. emission of this lane's frames; 2. its piece's product of F_t = A diag(b~_t), t >= 1
-    Mat<R, S> P;
+    Mat<R, S> P;                                           // the identity
 #pragma unroll
-    for (int i = 0; i < S; ++i)
+    for (int i = 0; i < S; ++i) {
+        P.e[i] = 1;
 #pragma unroll
-        for (int j = 0; j < S; ++j) P.v[i][j] = i == j ? (R)1 : (R)0;
+        for (int j = 0; j < S; ++j) P.v[i][j] = i == j ? (R)0.5 : (R)0;
+    }
     for (int t = t_begin; t < t_end; ++t) {
         const R* x = X + (size_t)(f0 + t) * D;
         R ll[S];
@@ -210,11 +249,12 @@ __global__ __launch_bounds__(64) void estep_wave_kernel(
         if (t >= 1) {
             Mat<R, S> F;
 #pragma unroll
-            for (int i = 0; i < S; ++i)
+            for (int i = 0; i < S; ++i) {
 #pragma unroll
                 for (int j = 0; j < S; ++j) F.v[i][j] = A[i][j] * b[j];
+                renorm_row(F, i, 0);
+            }
             P = matmul(P, F);
-            renorm(P);
         }
     }
 
@@ -224,14 +264,8 @@ __global__ __launch_bounds__(64) void estep_wave_kernel(
     for (int d = 1; d < 64; d <<= 1) {
         const Mat<R, S> lft = shfl_mat(pre, lane >= d ? lane - d : lane);
         const Mat<R, S> rgt = shfl_mat(suf, lane + d < 64 ? lane + d : lane);
-        if (lane >= d) {
-            pre = matmul(lft, pre);
-            renorm(pre);
-        }
-        if (lane + d < 64) {
-            suf = matmul(suf, rgt);
-            renorm(suf);
-        }
+        if (lane >= d) pre = matmul(lft, pre);
+        if (lane + d < 64) suf = matmul(suf, rgt);
     }
     // exclusive: what lies left of this lane's first frame / right of its last one
     const Mat<R, S> pre_x = shfl_mat(pre, lane >= 1 ? lane - 1 : 0);
@@ -260,12 +294,26 @@ __global__ __launch_bounds__(64) void estep_wave_kernel(
                 al_at(0)[s] = a0[s];
             }
         } else {
+            // alpha^_0 pre_x, the rows brought to the largest exponent among those alpha^_0 uses
+            int er = kNone;
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                const int ei = a0[i] > 0 && pre_x.e[i] != kNone ? pre_x.e[i] + Ops<R>::expo(a0[i]) : kNone;
+                er = ei > er ? ei : er;
+            }
+            R w0[S];
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                int sh = pre_x.e[i] - er;
+                sh = sh < -4096 ? -4096 : sh;
+                w0[i] = a0[i] > 0 && pre_x.e[i] != kNone ? Ops<R>::scale(a0[i], sh) : (R)0;
+            }
             R sum = 0;
 #pragma unroll
             for (int j = 0; j < S; ++j) {
                 R acc = 0;
 #pragma unroll
-                for (int i = 0; i < S; ++i) acc += a0[i] * pre_x.v[i][j];
+                for (int i = 0; i < S; ++i) acc += w0[i] * pre_x.v[i][j];
                 v[j] = acc;
                 sum += acc;
             }
@@ -297,13 +345,36 @@ __global__ __launch_bounds__(64) void estep_wave_kernel(
     }
 
     // ---- 4b. backward over this lane's frames: beta of its last frame = suf_x 1
+    // beta is carried on the scale of the sequential recursion, sum_i alpha^_t(i) beta_t(i) = 1:
+    // the states that hold the posterior mass then have a beta of order 1 / alpha^, whatever the
+    // others' are (a state the past has all but ruled out and the future favours by e^100 has a
+    // large beta and a tiny alpha; scaled to the largest beta instead, the states that matter
+    // would be the ones to underflow).  Entries beyond the dtype's range are held at its largest
+    // finite value: their alpha^ is below its smallest, and 0 x finite is the 0 the sequential
+    // recursion gets there.  v is alpha^ of this lane's last frame.
     R beta[S];
+    {
+        int eb = kNone;
 #pragma unroll
-    for (int i = 0; i < S; ++i) {
-        R acc = 0;
+        for (int i = 0; i < S; ++i) {
+            const int ei = v[i] > 0 && suf_x.e[i] != kNone ? suf_x.e[i] + Ops<R>::expo(v[i]) : kNone;
+            eb = ei > eb ? ei : eb;
+        }
+        R tot = 0, braw[S];
 #pragma unroll
-        for (int j = 0; j < S; ++j) acc += suf_x.v[i][j];
-        beta[i] = (lane == 63 || (lane + 1) * C >= T) ? (R)1 : acc;
+        for (int i = 0; i < S; ++i) {
+            R acc = 0;
+#pragma unroll
+            for (int j = 0; j < S; ++j) acc += suf_x.v[i][j];
+            int sh = eb != kNone ? suf_x.e[i] - eb : 0;
+            sh = sh < -4096 ? -4096 : sh > 4096 ? 4096 : sh;
+            braw[i] = suf_x.e[i] != kNone ? Ops<R>::finite(Ops<R>::scale(acc, sh)) : (R)0;
+            tot += v[i] * braw[i];
+        }
+        const R ti = tot > 0 ? Ops<R>::rcp(tot) : (R)1;
+#pragma unroll
+        for (int i = 0; i < S; ++i)
+            beta[i] = (lane == 63 || (lane + 1) * C >= T) ? (R)1 : Ops<R>::finite(braw[i] * ti);
     }
     R xi[S][S], post[S], start[S];
 #pragma unroll
@@ -352,7 +423,8 @@ __global__ __launch_bounds__(64) void estep_wave_kernel(
             const R bi = bm > 0 ? Ops<R>::rcp(bm) : (R)1;
 #pragma unroll
             for (int i = 0; i < S; ++i) {
-                beta[i] = nb[i] * bi;
+                // (tot = sum_i alpha^_{t-1}(i) nb(i): the scale on which alpha^ beta sums to 1)
+                beta[i] = tot > 0 ? Ops<R>::finite(nb[i] * ti) : nb[i] * bi;
 #pragma unroll
                 for (int j = 0; j < S; ++j) xi[i][j] += e[i][j] * ti;
             }
@@ -485,7 +557,8 @@ int srx_wave_estep(srx_context* h, const void* X, int dtype, const int64_t* off,
                    const int32_t* utt_model, const srx_models_t* md, double* out_stats, hipStream_t st) {
     constexpr int64_t kMaxUtts = 2048;
     const int S = md->n_states, D = md->n_features;
-    if (S > 4 || D > 256 || U <= 0 || U > kMaxUtts || n_frames <= 0) return SRX_EUNSUPPORTED;
+    // (n_frames: the row exponents of a product over T frames stay far inside 32 bits)
+    if (S > 4 || D > 256 || U <= 0 || U > kMaxUtts || n_frames <= 0 || n_frames > (1 << 17)) return SRX_EUNSUPPORTED;
     return dtype == SRX_F64 ? launch_wave<double>(h, X, off, U, n_frames, utt_model, md, out_stats, st)
                             : launch_wave<float>(h, X, off, U, n_frames, utt_model, md, out_stats, st);
 }

@@ -61,6 +61,13 @@ Tables<T> carve_tables(void* base, int M, int S, int D) {
     return t;
 }
 
+// beta of the scaled backward recursion is of order 1 / alpha^ for a state: where alpha^ has
+// underflowed to zero, beta may pass the dtype's largest value, and 0 x infinity would poison
+// the frame's posteriors and every sum they enter.  Held at the largest finite value the
+// product is the zero that alpha^ already stands for.
+__device__ __forceinline__ float finite_max(float x) { return fminf(x, 3.4028234664e38f); }
+__device__ __forceinline__ double finite_max(double x) { return fmin(x, 1.7976931348623157e308); }
+
 template <typename T>
 __global__ void prep_kernel(srx_models_t md, T* mu, T* hinv, T* cst, T* A, T* pi, T* logA,
                             T* logpi) {
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(kBlock) void fb_chain_kernel(T* __restrict__ loglik
                     s += w;
                     xi[i] += al * w;
                 });
-                beta = s * ci;
+                beta = finite_max(s * ci);
             }
             T g = al * beta;
             T gs = sub_sum<T, SP>(g);
@@ -907,7 +914,7 @@ __global__ __launch_bounds__(64) void fb_lane_kernel(
                     acc += w;
                     if constexpr (STATS) xi[i][j] += arow[i] * w;
                 }
-                beta[i] = acc * ci;
+                beta[i] = finite_max(acc * ci);
             }
         }
         float g[S], gs = 0.f;
@@ -1268,7 +1275,7 @@ __global__ __launch_bounds__(64) void posteriors_lane_kernel(
                     float acc = 0.f;
 #pragma unroll
                     for (int j = 0; j < S; ++j) acc += A[i][j] * bb[j];
-                    beta[i] = last ? cinv[k] : acc * cinv[k];
+                    beta[i] = last ? cinv[k] : finite_max(acc * cinv[k]);
                     g[i] = al[k][i] * beta[i];
                     gs += g[i];
                 }
@@ -1424,7 +1431,7 @@ __global__ __launch_bounds__(64) void fb_lane_f64_kernel(
                         acc += w;
                         xi[i][j] += arow[i] * w;
                     }
-                    beta[i] = acc * ci;
+                    beta[i] = finite_max(acc * ci);
                 }
                 g[i] = arow[i] * beta[i];
                 gs += g[i];

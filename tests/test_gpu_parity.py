@@ -1050,6 +1050,86 @@ def test_small_job_estep_paths_agree_with_oracle(sra, ctx, M, S, D):
         assert np.abs(res[dtype, "lane"] - res[dtype, "fused"]).max() <= 2 * tol * scale
 
 
+@pytest.mark.parametrize("path", ["wave", "lane", "fused", "generic"])
+@pytest.mark.parametrize("dtype,tol", [("float32", 2e-5), ("float64", 1e-9)])
+def test_estep_forced_path_through_unlikely_states(sra, ctx, dtype, tol, path):
+    """A strict left-to-right chain of four states whose data sits on the last state from the
+    first frame on: the chain has to walk through three states that each cost e^-60 per frame.
+    Every frame still has a float32 scale factor (e^-60), so the scaled recursions are defined,
+    but two things go out of float32's range on the way.  (1) A product of three frames'
+    transfer matrices holds the row of start state 0 (the only one the chain can be in) at
+    e^-120 of the row of start state 3: the wave kernel's matrices carry an exponent per row.
+    (2) beta of the states the chain is NOT in grows like 1 / alpha^ and passes the largest
+    float (the reference's recursion in float32 gives 0 x inf = NaN there): every kernel holds
+    beta at the largest finite value, and the wave kernel scales it by sum alpha^ beta = 1
+    like the sequential recursion, not by its largest entry."""
+    S, D = 4, 13
+    rng = np.random.default_rng(123)
+    A = np.zeros((S, S))
+    for i in range(S):
+        A[i, i] = 0.6 if i + 1 < S else 1.0
+        if i + 1 < S:
+            A[i, i + 1] = 0.4
+    pi = np.zeros(S); pi[0] = 1.0
+    means = np.zeros((S, D))
+    for i in range(S - 1):
+        means[i] = (3.0 + 0.1 * i) * (1 if i % 2 == 0 else -1)      # 13 * 3^2 / 2 = 58 nats from the data
+    prm = ho.Params(pi, A, means, np.ones((S, D)))
+    lengths = np.array([130, 65, 200, 320, 5, 64])
+    X = 0.3 * rng.standard_normal((int(lengths.sum()), D))
+    bank = _bank(sra, ctx, [prm])
+    data = sra.Ragged(ctx, X, lengths, dtype=dtype)
+    generic = path == "generic"
+    ctx.set_estep_path("auto" if generic else path)
+    try:
+        got = bank.unpack_stats(bank.estep(data, generic=generic))[0]
+    finally:
+        ctx.set_estep_path("auto")
+    st, lps = ho.estep(prm, X, [int(t) for t in lengths], loops=False)
+    lp = float(np.sum(lps))
+    assert np.isfinite(got["logprob"]) and abs(got["logprob"] - lp) <= tol * abs(lp)
+    for k in ("start", "trans", "post", "obs", "obs**2"):
+        np.testing.assert_allclose(got[k], st[k], rtol=tol, atol=tol * max(1.0, np.abs(st[k]).max()), err_msg=k)
+    if path == "wave":          # (once per dtype: the posteriors of the same batch)
+        plp, gamma = bank.posteriors(data)
+        gamma = gamma.cpu().numpy()
+        assert np.isfinite(gamma).all()
+        np.testing.assert_allclose(gamma.sum(axis=1), 1.0, atol=1e-5)
+        np.testing.assert_allclose(plp.cpu().numpy(), lps, rtol=tol)
+        _, ref = ho.score_posteriors(prm, X, [int(t) for t in lengths], loops=False)
+        np.testing.assert_allclose(gamma, ref, atol=5e-5 if dtype == "float32" else 1e-9)
+
+
+@pytest.mark.parametrize("S,D", [(3, 26), (2, 13)])
+def test_wave_estep_left_to_right_model_on_foreign_data(sra, ctx, S, D):
+    """A left-to-right model scored on frames it was not drawn from (float64; in float32 such
+    frames have no density in any kernel).  The likelihood of a run of frames then differs
+    between start states by hundreds of nats, most of them start states the chain is not in:
+    the transfer-matrix products of the wave kernel have to carry every row on a scale of its
+    own to keep the one that the forward vector selects."""
+    rng = np.random.default_rng(5 * S + D)
+    prm = ho.random_params(rng, S, D)
+    A = np.triu(prm.A) + 1e-300
+    A = np.triu(A / A.sum(axis=1, keepdims=True))
+    pi = np.zeros(S); pi[0] = 1.0
+    prm = ho.Params(pi, A / A.sum(axis=1, keepdims=True), 3.0 * prm.means, prm.covars)
+    lengths = rng.integers(1, 500, size=24)
+    lengths[:4] = [1, 2, 64, 499]
+    X = 2.0 * rng.standard_normal((int(lengths.sum()), D))
+    bank = _bank(sra, ctx, [prm])
+    data = sra.Ragged(ctx, X, lengths, dtype="float64")
+    ctx.set_estep_path("wave")
+    try:
+        got = bank.unpack_stats(bank.estep(data))[0]
+    finally:
+        ctx.set_estep_path("auto")
+    st, lps = ho.estep(prm, X, [int(t) for t in lengths], loops=False)
+    lp = float(np.sum(lps))
+    assert np.isfinite(got["logprob"]) and abs(got["logprob"] - lp) <= 1e-9 * abs(lp)
+    for k in ("start", "trans", "post", "obs", "obs**2"):
+        np.testing.assert_allclose(got[k], st[k], rtol=1e-9, atol=1e-9 * max(1.0, np.abs(st[k]).max()), err_msg=k)
+
+
 @pytest.mark.parametrize("M,S,D,tmax", [(1, 1, 1, 90), (6, 3, 26, 240), (5, 2, 9, 700), (4, 4, 39, 130),
                                         (2, 3, 100, 64)])
 def test_wave_per_utterance_estep_against_oracle(sra, ctx, M, S, D, tmax):
