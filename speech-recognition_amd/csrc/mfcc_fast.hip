@@ -123,7 +123,10 @@ __device__ constexpr float kSin32[16] = {
 
 // In-place radix-2 DIT on registers (Q = 16 or 32).  Input must already sit in
 // bit-reversed order (a[brev(n)] = x[n]); the twiddles W_Q^q are compile-time constants.
-template <int Q>
+// NR < Q: inputs n >= NR are known to be zero (a frame shorter than the transform: the tail of
+// the zero padding), so the first-stage butterflies whose second input is one of them are
+// copies.
+template <int Q, int NR = Q>
 __device__ __forceinline__ void fft_regs(v2f (&z)[Q]) {
 #pragma unroll
     for (int s = 1; s <= ilog2(Q); ++s) {
@@ -134,6 +137,10 @@ __device__ __forceinline__ void fft_regs(v2f (&z)[Q]) {
             for (int jj = 0; jj < half; ++jj) {
                 const int i0 = k + jj, i1 = i0 + half;
                 v2f t;
+                if (s == 1 && brev(i1, ilog2(Q)) >= NR) {
+                    z[i1] = z[i0];
+                    continue;
+                }
                 if (jj == 0) {
                     t = z[i1];
                 } else if (2 * jj == half) {     // W = -i: t = (z.y, -z.x), folded into the two adds
@@ -166,7 +173,7 @@ struct cf {
     float x, y;
 };
 
-template <int Q>
+template <int Q, int NR = Q>
 __device__ __forceinline__ void fft_regs(cf (&z)[Q]) {
 #pragma unroll
     for (int s = 1; s <= ilog2(Q); ++s) {
@@ -177,7 +184,9 @@ __device__ __forceinline__ void fft_regs(cf (&z)[Q]) {
             for (int jj = 0; jj < half; ++jj) {
                 const int i0 = k + jj, i1 = i0 + half;
                 const cf a = z[i0], b = z[i1];
-                if (jj == 0) {
+                if (s == 1 && brev(i1, ilog2(Q)) >= NR) {      // (zero input: see the packed form)
+                    z[i1] = a;
+                } else if (jj == 0) {
                     z[i0] = cf{a.x + b.x, a.y + b.y};
                     z[i1] = cf{a.x - b.x, a.y - b.y};
                 } else if (2 * jj == half) {     // W = -i: t = (b.y, -b.x)
@@ -277,7 +286,10 @@ template <> struct FastCfg<32> {
 // Workgroups a CU holds at once (registers and LDS are sized for it)
 template <int P> constexpr int kWgPerCu = P == 16 ? 3 : 2;
 
-template <int P>
+// NR: rows of 32 samples that a frame reaches into (ceil(n_used / 32)); P when not known at
+// compile time.  Rows from NR on meet the window's zero tail: they are neither loaded nor
+// multiplied, and the first transform stage knows its zeros.
+template <int P, int NR>
 __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * frames_per_block<P>() + 255) / 256) void cepstra_fast_kernel(
     const float* __restrict__ audio, const int32_t* __restrict__ row_start, int64_t n_rows, int64_t total,
     FastDev c, float* __restrict__ cep) {
@@ -372,7 +384,7 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
         const unsigned rel = start >= 0 ? (unsigned)start - (unsigned)p0 : 0u;
         const unsigned voff = (rel + 2u * (unsigned)j) * 4u;
 #pragma unroll
-        for (int n1 = 0; n1 < P; ++n1) {
+        for (int n1 = 0; n1 < NR; ++n1) {
             const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff + 128u * n1, 0, 0);
             xr[2 * n1] = __uint_as_float(v[0]);
             xr[2 * n1 + 1] = __uint_as_float(v[1]);
@@ -388,13 +400,17 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
         cpx z1[P];
 #pragma unroll
         for (int n1 = 0; n1 < P; ++n1) {
+            if (n1 >= NR) {
+                z1[brev(n1, ilog2(P))] = cpx{0.f, 0.f};
+                continue;
+            }
             const int i0 = 32 * n1 + 2 * j;
             const float2 wv = *(const float2*)(s_win + i0);
             z1[brev(n1, ilog2(P))] = cpx{mul_zero_wins(xc[2 * n1], wv.x), mul_zero_wins(xc[2 * n1 + 1], wv.y)};
         }
         fetch(next_start, next_b, xc);
         if (any) {
-        fft_regs<P>(z1);
+        fft_regs<P, NR>(z1);
         // ---- 2. twiddle W_H^(j k1) and 3. transpose through LDS: Y[k1][j]
 #pragma unroll
         for (int k1 = 0; k1 < P; ++k1) Y[k1 * 17 + j] = twiddled(s_tw2[k1 * 16 + j], z1[k1], k1 == 0);
@@ -634,7 +650,7 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
     }
 }
 
-template <int P>
+template <int P, int NR>
 int launch_fast(srx_context* h, const float* audio, const int64_t* so, int64_t U, int64_t total,
                 const FastDev& d, float* cep, hipStream_t st) {
     constexpr int H = 16 * P, N = 2 * H, YS = P * 17;
@@ -645,7 +661,7 @@ int launch_fast(srx_context* h, const float* audio, const int64_t* so, int64_t U
     const size_t lds = tables + per_frame * frames_per_block<P>();
 
     if (lds > 160 * 1024) return SRX_EUNSUPPORTED;
-    auto kern = cepstra_fast_kernel<P>;
+    auto kern = cepstra_fast_kernel<P, NR>;
     SRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // start sample of every cepstra row (rows as in srx_mfcc_batch: total / hop + 1)
     const int64_t n_rows = total / d.hop + 1;
@@ -698,6 +714,11 @@ int srx_mfcc_fast_cepstra(srx_context* h, srx_mfcc_plan* p, const float* audio, 
     d.log_mult = (float)c.log_mult;
     d.window = (const float*)p->window[0];
     d.tw = (const float2*)p->tw_full;
-    return c.nfft == 512 ? launch_fast<16>(h, audio, so, U, total, d, cep, st)
-                         : launch_fast<32>(h, audio, so, U, total, d, cep, st);
+    // (the two shapes the plans are made for: 400 samples in 512 points, 551 in 1024)
+    const int rows = (d.n_used + 31) / 32;
+    if (c.nfft == 512)
+        return rows == 13 ? launch_fast<16, 13>(h, audio, so, U, total, d, cep, st)
+                          : launch_fast<16, 16>(h, audio, so, U, total, d, cep, st);
+    return rows == 18 ? launch_fast<32, 18>(h, audio, so, U, total, d, cep, st)
+                      : launch_fast<32, 32>(h, audio, so, U, total, d, cep, st);
 }
