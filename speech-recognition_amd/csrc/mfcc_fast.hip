@@ -310,7 +310,8 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
         for (int i = threadIdx.x; i < c.nq * 256; i += blockDim.x) s_w4_lds[i] = c.mm_w[i];
         for (int i = threadIdx.x; i < 64 * c.kk; i += blockDim.x) s_dctA_lds[i] = c.mm_dct[i];
     }
-    v2f* s_tw2 = (v2f*)(s_meta + 48);                 // [P][16]: W_H^(j k1)
+    float* s_zero = (float*)(s_meta + 48);            // four zeros: the partial sum a filter group does not have
+    v2f* s_tw2 = (v2f*)(s_meta + 52);                 // [P][16]: W_H^(j k1)
     float* s_frames = (float*)(s_tw2 + P * 16);
     // A frame's tile holds the transpose buffer Y / the spectrum Z first; once Z has
     // been read, the same floats hold pw [H+4], the log-mel row [4 kk] and a quarter
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
     const int part_off = kLm + 4 * c.kk;
     for (int i = threadIdx.x; i < H / 2; i += blockDim.x) s_tw[i] = v2f{c.tw[i].x, c.tw[i].y};
     for (int i = threadIdx.x; i < N; i += blockDim.x) s_win[i] = i < c.n_used ? c.window[i] : 0.f;
-    for (int i = threadIdx.x; i < 48; i += blockDim.x) s_meta[i] = c.mm_meta[i];
+    for (int i = threadIdx.x; i < 52; i += blockDim.x) s_meta[i] = i < 48 ? c.mm_meta[i] : 0;
     for (int i = threadIdx.x; i < P * 16; i += blockDim.x)
     {
         const float2 w = c.tw[2 * (((i & 15) * (i >> 4)) & (H - 1))];
@@ -546,22 +547,33 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
         const float log2_scale = (float)scale_d, log2_scale_lo = (float)(scale_d - (double)log2_scale);
         if (blk < c.groups) {
             // (a group's blocks are read at once, not one after the other's answer)
-            f32x4 e = {0.f, 0.f, 0.f, 0.f};
+            // (a piece the group does not have is read from four zeros: one select of an
+            // address instead of four of values)
+            f32x4 e = *(const f32x4*)part_at(grp_first, col);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 v = *(const f32x4*)part_at(grp_first + (i < grp_cnt ? i : grp_cnt - 1), col);
-                e += i < grp_cnt ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int i = 1; i < 4; ++i)
+                e += *(const f32x4*)(i < grp_cnt ? part_at(grp_first + i, col) : s_zero);
             for (int nb = grp_first + 4; nb < grp_first + grp_cnt; ++nb) e += *(const f32x4*)part_at(nb, col);
             f32x4 l;
+            // log_mult * log10(v) on the base-2 logarithm instruction.  Exact zeros become eps, and
+            // values below 2^-96 (denormals among them, which the instruction does not take) are
+            // scaled up first -- on a path of its own that a wave takes only when one of its
+            // energies is that small (silence, digital zero), not in every step.
+            const bool small = e[0] < 0x1p-96f || e[1] < 0x1p-96f || e[2] < 0x1p-96f || e[3] < 0x1p-96f;
+            if (__ballot(small) == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                // log_mult * log10(v) on the base-2 logarithm instruction; values below 2^-96
-                // (denormals among them, which the instruction does not take) are scaled up first
-                const float v = e[i] == 0.f ? 2.220446049250313e-16f : e[i];
-                const bool tiny = v < 0x1p-96f;
-                const float l2 = __builtin_amdgcn_logf(tiny ? v * 0x1p32f : v) - (tiny ? 32.f : 0.f);
-                l[i] = fmaf(l2, log2_scale, l2 * log2_scale_lo);
+                for (int i = 0; i < 4; ++i) {
+                    const float l2 = __builtin_amdgcn_logf(e[i]);
+                    l[i] = fmaf(l2, log2_scale, l2 * log2_scale_lo);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = e[i] == 0.f ? 2.220446049250313e-16f : e[i];
+                    const bool tiny = v < 0x1p-96f;
+                    const float l2 = __builtin_amdgcn_logf(tiny ? v * 0x1p32f : v) - (tiny ? 32.f : 0.f);
+                    l[i] = fmaf(l2, log2_scale, l2 * log2_scale_lo);
+                }
             }
             *(f32x4*)(lm_col + 4 * blk) = l;
         } else if (blk < c.kk) {
@@ -654,7 +666,7 @@ template <int P, int NR>
 int launch_fast(srx_context* h, const float* audio, const int64_t* so, int64_t U, int64_t total,
                 const FastDev& d, float* cep, hipStream_t st) {
     constexpr int H = 16 * P, N = 2 * H, YS = P * 17;
-    const size_t tables = sizeof(float2) * (H / 2) + sizeof(float2) * P * 16 + 4 * ((size_t)N + 48) +
+    const size_t tables = sizeof(float2) * (H / 2) + sizeof(float2) * P * 16 + 4 * ((size_t)N + 52) +
                           (FastCfg<P>::lds_weights ? 4 * ((size_t)d.nq * 256 + 64 * (size_t)d.kk) : 0);
     const size_t per_frame = 4 * (size_t)2 * YS;
     if ((size_t)(H + 4) + 4 * (size_t)d.kk + 64 > (size_t)2 * YS) return SRX_EUNSUPPORTED;
