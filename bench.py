@@ -445,8 +445,8 @@ def main():
         extra["mfcc"] = {"frames_per_s": raw_frames * world / dtf, "frames_per_gpu": raw_frames,
                          "ms": dtf * 1e3,
                          "hbm_frac": raw_frames * 796 / dtf / 1e9 / HBM_PEAK_GBS,
-                         "bound": "vector ALU issue (832 vector + 112 LDS + 44 matrix instructions per wave-step of "
-                                  "4 frames; the three waves of a SIMD keep its vector pipe busy 0.93 of the kernel's "
+                         "bound": "vector ALU issue (749 vector + 108 LDS + 44 matrix instructions per wave-step of "
+                                  "4 frames; the three waves of a SIMD keep its vector pipe busy 0.90 of the kernel's "
                                   "time by the shader counters); HBM line shown for reference",
                          "flop_per_frame_executed": flop_per_frame,
                          "vector_peak_frac": raw_frames * flop_per_frame / dtf / 157.3e12,
