@@ -149,7 +149,7 @@ template <typename R, int S>
 __global__ __launch_bounds__(64) void estep_wave_kernel(
     const R* __restrict__ X, const int64_t* __restrict__ off, int64_t U,
     const int32_t* __restrict__ utt_model, srx_models_t md, int with_obs, R* __restrict__ scratch,
-    double* __restrict__ records, int rec_size) {
+    double* __restrict__ records, int rec_size, int lds_frames, int red_offset) {
     const int D = md.n_features;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // [S][DP]{mean, -0.5 / var}: DP = D rounded up to whole blocks of kBlk features, the padding
@@ -197,7 +197,14 @@ __global__ __launch_bounds__(64) void estep_wave_kernel(
     const int C = (T + 63) / 64;
     const int t_begin = lane * C < T ? lane * C : T;
     const int t_end = t_begin + C < T ? t_begin + C : T;
-    R* fr = scratch + (size_t)f0 * kFrameWords<S>;
+    // The per-frame arrays of an utterance of at most lds_frames frames stay in LDS (behind the
+    // tables): every one of them is written and read back within this wave, and a round trip to
+    // memory per phase is most of what so small a job waits for.  Longer utterances use the
+    // global scratch area.
+    R* fr = T <= lds_frames ? s_cst + S : scratch + (size_t)f0 * kFrameWords<S>;
+    // (behind the frames: the area the cross-lane sums go through)
+    constexpr int kRedStride = 65;       // doubles per quantity: lanes reading different rows hit different banks
+    double* red = (double*)(smem + red_offset);
     auto bt_at = [&](int t) { return fr + (size_t)t * kFrameWords<S>; };             // b~[S]
     auto al_at = [&](int t) { return fr + (size_t)t * kFrameWords<S> + S; };         // alpha^[S]
     auto ga_at = [&](int t) { return fr + (size_t)t * kFrameWords<S> + 2 * S; };     // gamma[S]
@@ -211,50 +218,68 @@ __global__ __launch_bounds__(64) void estep_wave_kernel(
 #pragma unroll
         for (int j = 0; j < S; ++j) P.v[i][j] = i == j ? (R)0.5 : (R)0;
     }
-    for (int t = t_begin; t < t_end; ++t) {
-        const R* x = X + (size_t)(f0 + t) * D;
-        R ll[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) ll[s] = 0;
-        // (a block of features is requested at once -- every lane reads its own row, so a load
-        // is a round trip to the cache for 64 different lines -- and the padding repeats the last
-        // feature under a zero weight)
-        for (int d0 = 0; d0 < DP; d0 += kBlk) {
-            R xv[kBlk];
+    {
+        // (A block of features is requested at once -- every lane reads its own row, so a load is
+        // a round trip to the cache for 64 different lines -- and the block after it, of this
+        // frame or the next, is requested before this one is used: the loads are issued whatever
+        // the lane's range is, from a clamped frame, because a load under a branch is waited for
+        // where the branch ends.  The padding repeats the last feature under a zero weight.)
+        auto load_blk = [&](int t, int d0, R (&xv)[kBlk]) {
+            const R* x = X + (size_t)(f0 + (t < T ? t : T - 1)) * D;
 #pragma unroll
             for (int k = 0; k < kBlk; ++k) xv[k] = x[d0 + k < D ? d0 + k : D - 1];
+        };
+        R cur[kBlk], nxt[kBlk], ll[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) ll[s] = 0;
+        int t = t_begin, d0 = 0;
+        load_blk(t, 0, cur);
+        while (t < t_end) {
+            int nt = t, nd = d0 + kBlk;
+            if (nd >= DP) {
+                nd = 0;
+                nt = t + 1;
+            }
+            load_blk(nt, nd, nxt);
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const R* tb = s_tab + 2 * (s * DP + d0);
 #pragma unroll
                 for (int k = 0; k < kBlk; ++k) {
-                    const R c = xv[k] - tb[2 * k];
+                    const R c = cur[k] - tb[2 * k];
                     ll[s] += tb[2 * k + 1] * c * c;
                 }
             }
-        }
-        R mx = ll[0] + s_cst[0];
+            if (nd == 0) {                                 // the frame's last block
+                R mx = ll[0] + s_cst[0];
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            ll[s] += s_cst[s];
-            mx = ll[s] > mx ? ll[s] : mx;
-        }
-        R b[S];
+                for (int s = 0; s < S; ++s) {
+                    ll[s] += s_cst[s];
+                    mx = ll[s] > mx ? ll[s] : mx;
+                }
+                R b[S];
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            b[s] = Ops<R>::exp(ll[s] - mx);
-            bt_at(t)[s] = b[s];
-        }
-        *mx_at(t) = mx;
-        if (t >= 1) {
-            Mat<R, S> F;
+                for (int s = 0; s < S; ++s) {
+                    b[s] = Ops<R>::exp(ll[s] - mx);
+                    bt_at(t)[s] = b[s];
+                    ll[s] = 0;
+                }
+                *mx_at(t) = mx;
+                if (t >= 1) {
+                    Mat<R, S> F;
 #pragma unroll
-            for (int i = 0; i < S; ++i) {
+                    for (int i = 0; i < S; ++i) {
 #pragma unroll
-                for (int j = 0; j < S; ++j) F.v[i][j] = A[i][j] * b[j];
-                renorm_row(F, i, 0);
+                        for (int j = 0; j < S; ++j) F.v[i][j] = A[i][j] * b[j];
+                        renorm_row(F, i, 0);
+                    }
+                    P = matmul(P, F);
+                }
             }
-            P = matmul(P, F);
+#pragma unroll
+            for (int k = 0; k < kBlk; ++k) cur[k] = nxt[k];
+            t = nt;
+            d0 = nd;
         }
     }
 
@@ -431,37 +456,53 @@ __global__ __launch_bounds__(64) void estep_wave_kernel(
         }
     }
 
-    // ---- sums over the lanes (float64, fixed order) into the utterance's record
-    const double lp_all = wave_sum(lp);
+    // ---- sums over the lanes (float64, fixed order) into the utterance's record: every lane
+    // leaves its terms in LDS, lane q adds the 64 terms of quantity q (four running sums over
+    // the lanes 4k + j, then (s0 + s1) + (s2 + s3)) -- a sixth of the time of butterfly sums
+    // of 64-bit values through lane shuffles
+    {
+        constexpr int NQ = 2 * S + S * S + 1;
+        auto put = [&](int q, double v) { red[q * kRedStride + lane] = v; };
 #pragma unroll
-    for (int i = 0; i < S; ++i) {
-        const double ps = wave_sum((double)post[i]);
-        const double ss = wave_sum((double)start[i]);
-        if (lane == 0) {
-            rec[L.post + i] = with_obs ? ps : 0.0;
-            rec[L.start + i] = ss;
-        }
+        for (int i = 0; i < S; ++i) {
+            put(i, (double)post[i]);
+            put(S + i, (double)start[i]);
 #pragma unroll
-        for (int j = 0; j < S; ++j) {
-            const double xs = wave_sum((double)xi[i][j]);
-            if (lane == 0) rec[L.trans + i * S + j] = xs;
+            for (int j = 0; j < S; ++j) put(2 * S + i * S + j, (double)xi[i][j]);
         }
-    }
-    if (lane == 0) {
-        rec[L.nobs] = 1.0;
-        rec[L.logprob] = lp_all;
+        put(NQ - 1, lp);
+        wave_mem_sync();
+        if (lane < NQ) {
+            const double* row = red + lane * kRedStride;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 4
+            for (int k = 0; k < 64; k += 4) {
+                a0 += row[k];
+                a1 += row[k + 1];
+                a2 += row[k + 2];
+                a3 += row[k + 3];
+            }
+            const double tot = (a0 + a1) + (a2 + a3);
+            const int q = lane;
+            if (q < S) rec[L.post + q] = with_obs ? tot : 0.0;
+            else if (q < 2 * S) rec[L.start + (q - S)] = tot;
+            else if (q < NQ - 1) rec[L.trans + (q - 2 * S)] = tot;
+            else rec[L.logprob] = tot;
+        }
+        if (lane == 0) rec[L.nobs] = 1.0;
     }
     if (!with_obs) return;
 
-    // ---- 5. gamma^T [x | x^2]: lane = feature column (+ 64, ...), frames in order
+    // ---- 5. gamma^T [x | x^2]: lane = feature column.  With at most 32 features the wave holds
+    // several columns' worth of lanes: lane (part, d) adds the frames of its part, the parts are
+    // then added in order through LDS.  Wider rows: lanes d, d + 64, ..., all frames each.
     wave_mem_sync();                                       // gamma of every frame is in the scratch
-    for (int d = lane; d < D; d += 64) {
-        R o1[S], o2[S];
+    auto column = [&](int d, int ta, int tb, R (&o1)[S], R (&o2)[S]) {
 #pragma unroll
         for (int s = 0; s < S; ++s) o1[s] = o2[s] = 0;
         const R* x = X + (size_t)f0 * D + d;
-        int t = 0;
-        for (; t + 8 <= T; t += 8) {
+        int t = ta;
+        for (; t + 8 <= tb; t += 8) {
             R xv[8], gv[8][S];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -478,7 +519,7 @@ __global__ __launch_bounds__(64) void estep_wave_kernel(
                     o2[s] += gx * xv[k];
                 }
         }
-        for (; t < T; ++t) {
+        for (; t < tb; ++t) {
             const R xv = x[(size_t)t * D];
 #pragma unroll
             for (int s = 0; s < S; ++s) {
@@ -487,10 +528,46 @@ __global__ __launch_bounds__(64) void estep_wave_kernel(
                 o2[s] += gx * xv;
             }
         }
+    };
+    const int parts = D <= 32 ? 64 / D : 1;
+    if (parts > 1) {
+        const int np = parts < 8 ? parts : 8;              // (8 x 2S x 8 columns at most: fits `red`)
+        const int part = lane / D, d = lane % D;
+        const int per = (T + np - 1) / np;
+        R o1[S], o2[S];
+        const bool mine = part < np;
+        column(d, mine ? (part * per < T ? part * per : T) : 0, mine ? ((part + 1) * per < T ? (part + 1) * per : T) : 0,
+               o1, o2);
+        wave_mem_sync();                                   // (the sums above have been read out of `red`)
+        if (mine) {
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            rec[L.obs + s * D + d] = (double)o1[s];
-            rec[L.obs2 + s * D + d] = (double)o2[s];
+            for (int s = 0; s < S; ++s) {
+                red[((part * 2 * S) + s) * D + d] = (double)o1[s];
+                red[((part * 2 * S) + S + s) * D + d] = (double)o2[s];
+            }
+        }
+        wave_mem_sync();
+        if (part == 0) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                double a = 0.0, b = 0.0;
+                for (int q = 0; q < np; ++q) {
+                    a += red[((q * 2 * S) + s) * D + d];
+                    b += red[((q * 2 * S) + S + s) * D + d];
+                }
+                rec[L.obs + s * D + d] = a;
+                rec[L.obs2 + s * D + d] = b;
+            }
+        }
+    } else {
+        for (int d = lane; d < D; d += 64) {
+            R o1[S], o2[S];
+            column(d, 0, T, o1, o2);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                rec[L.obs + s * D + d] = (double)o1[s];
+                rec[L.obs2 + s * D + d] = (double)o2[s];
+            }
         }
     }
 }
@@ -534,12 +611,21 @@ int launch_wave(srx_context* h, const void* X, const int64_t* off, int64_t U, in
     int rc;
     if ((rc = srx_ws_ensure(h, WS_LATTICE, sizeof(R) * (size_t)n_frames * (3 * S + 1), (void**)&scratch))) return rc;
     if ((rc = srx_ws_ensure(h, WS_PARTIAL, sizeof(double) * (size_t)U * rec_size, (void**)&records))) return rc;
-    const size_t lds = sizeof(R) * ((size_t)2 * S * ((D + 15) / 16 * 16) + S);
+    const size_t lds_tab = sizeof(R) * ((size_t)2 * S * ((D + 15) / 16 * 16) + S);
+    // (frames of the longest utterance this call can hold, up to 48 KB: three workgroups per CU)
+    const size_t per_frame = sizeof(R) * (3 * (size_t)S + 1);
+    // (behind them 65 doubles per quantity summed over the lanes: at most 25 x 65 x 8 = 13 KB)
+    const size_t red_bytes = sizeof(double) * 65 * (2 * (size_t)S + (size_t)S * S + 1);
+    size_t room = (size_t)44 * 1024 > lds_tab ? (size_t)44 * 1024 - lds_tab : 0;
+    if ((size_t)n_frames * per_frame < room) room = (size_t)n_frames * per_frame;
+    const int lds_frames = (int)(room / per_frame);
+    const int red_offset = (int)((lds_tab + (size_t)lds_frames * per_frame + 15) / 16 * 16);
+    const size_t lds = (size_t)red_offset + red_bytes;
     const int with_obs = h->estep_stats != SRX_STATS_TRANSITIONS;
 #define SRX_CASE(s_)                                                                               \
     if (S == s_)                                                                                   \
         hipLaunchKernelGGL((estep_wave_kernel<R, s_>), dim3((unsigned)U), dim3(64), lds, st, (const R*)X, \
-                           off, U, utt_model, *md, with_obs, scratch, records, rec_size);
+                           off, U, utt_model, *md, with_obs, scratch, records, rec_size, lds_frames, red_offset);
     SRX_CASE(1) SRX_CASE(2) SRX_CASE(3) SRX_CASE(4)
 #undef SRX_CASE
     hipLaunchKernelGGL(wave_reduce_kernel, dim3((unsigned)(M * ((rec_size + 63) / 64))), dim3(64), 0, st,
