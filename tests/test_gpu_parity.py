@@ -1075,7 +1075,8 @@ def test_estep_forced_path_through_unlikely_states(sra, ctx, dtype, tol, path):
     for i in range(S - 1):
         means[i] = (3.0 + 0.1 * i) * (1 if i % 2 == 0 else -1)      # 13 * 3^2 / 2 = 58 nats from the data
     prm = ho.Params(pi, A, means, np.ones((S, D)))
-    lengths = np.array([130, 65, 200, 320, 5, 64])
+    # (600 and 1000 frames: beyond what the wave kernel keeps in LDS in float64 / float32)
+    lengths = np.array([130, 65, 200, 320, 5, 64, 600, 1000])
     X = 0.3 * rng.standard_normal((int(lengths.sum()), D))
     bank = _bank(sra, ctx, [prm])
     data = sra.Ragged(ctx, X, lengths, dtype=dtype)
