@@ -21,20 +21,32 @@ from .hmm import GaussianHMM
 from .recognizer import WORDS, _word_of, classify, extract_mfcc_calc, score_matrix, word_files   # noqa: F401
 
 
+def _resample(y, sr, sample_rate):
+    """Band-limited resampling of a float32 signal from ``sr`` to ``sample_rate`` Hz by a
+    polyphase FIR filter (scipy.signal.resample_poly: Kaiser window, ratio reduced by the greatest
+    common divisor), ceil(n * sample_rate / sr) samples out -- the length librosa.load returns.
+    librosa's own default is the soxr library's "soxr_hq" filter, which is not in the image:
+    the two agree to the filters' stop-band ripple, not bit for bit (parity unpinned)."""
+    from math import gcd
+    from scipy.signal import resample_poly
+    g = gcd(int(sr), int(sample_rate))
+    return resample_poly(y.astype(np.float64), int(sample_rate) // g, int(sr) // g).astype(np.float32)
+
+
 def _load(audio_path, sample_rate):
-    """librosa.load(path, sr=sample_rate): float32 mono in [-1, 1).  A file stored at
-    another rate would be resampled by librosa (soxr); that is not provided here."""
+    """librosa.load(path, sr=sample_rate): float32 mono in [-1, 1), resampled to ``sample_rate``
+    when the file is stored at another rate (HMM_lib.py:12)."""
     path = str(audio_path)
     if not path.endswith(".wav"):
         path += ".wav"
     sr, y = wavfile.read(path)
-    if sample_rate is not None and int(sr) != int(sample_rate):
-        raise ValueError(f"{path} is stored at {sr} Hz, not {sample_rate} Hz: resampling is "
-                         "not provided")
     if np.issubdtype(y.dtype, np.integer):
         y = y.astype(np.float32) / float(np.iinfo(y.dtype).max + 1)
     y = np.asarray(y, dtype=np.float32)
-    return y.mean(axis=1) if y.ndim == 2 else y
+    y = y.mean(axis=1) if y.ndim == 2 else y
+    if sample_rate is not None and int(sr) != int(sample_rate):
+        y = _resample(y, sr, sample_rate)
+    return y
 
 
 def features_of(audio_paths, sample_rate, n_mfcc=13, dtype="float32"):

@@ -304,3 +304,21 @@ def test_two_rank_trainer_step_gloo():
         p.join(180)
         assert p.exitcode == 0
     assert ret.get(0) and ret.get(1)
+
+
+def test_hmm_lib_resamples_on_load(tmp_path):
+    """HMM_lib.py:12 loads with librosa.load(path, sr=sample_rate): a file stored at another rate
+    comes back at the requested one, ceil(n * ratio) samples long, with its tone where it was."""
+    from scipy.io import wavfile
+    import speech_recognition_amd as sra
+    n, sr = 16000, 16000
+    t = np.arange(n) / sr
+    y = (0.5 * np.sin(2 * np.pi * 1000.0 * t)).astype(np.float32)
+    wavfile.write(str(tmp_path / "tone.wav"), sr, y)
+    out = sra.hmm_lib._load(str(tmp_path / "tone"), 22050)
+    assert out.dtype == np.float32 and len(out) == -(-n * 22050 // sr)
+    spec = np.abs(np.fft.rfft(out * np.hanning(len(out))))
+    assert abs(np.argmax(spec) * 22050.0 / len(out) - 1000.0) < 2.0
+    assert abs(np.abs(out[2000:-2000]).max() - 0.5) < 5e-3
+    same = sra.hmm_lib._load(str(tmp_path / "tone"), 16000)
+    assert np.array_equal(same, y)
