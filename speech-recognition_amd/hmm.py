@@ -363,6 +363,7 @@ class MyGaussianHMM:
 
     def _mstep_from_dict(self, stats, mode):
         bank = self._bank()
+        self.__dict__.pop("_dev_bank", None)
         rec = bank.ctx.tensor(self._pack_stats(stats)[None])
         bank.mstep(rec, self._priors(), mode)
         self._pull(bank)
@@ -392,6 +393,10 @@ class MyGaussianHMM:
         import torch
         data = self._data(X, lengths)
         bank = self._bank()
+        # (the iterations rewrite the bank in place: until _pull has brought the host arrays
+        # up to date it is not the device copy of what they hold -- a fit that is interrupted
+        # must not leave it behind as one)
+        self.__dict__.pop("_dev_bank", None)
         pri = self._priors()
         self.monitor_ = ConvergenceMonitor(self.tol, self.n_iter, self.verbose)
         # The host never waits for the iteration it has just queued: the log-probability of
