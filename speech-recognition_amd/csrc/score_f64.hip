@@ -71,13 +71,22 @@ __global__ void f64_prep_kernel(srx_models_t md, int SP, int n_tiles, int R, dou
 template <int SP, int R>
 __global__ __launch_bounds__(256) void score_f64_kernel(
     const double* __restrict__ X, const int64_t* __restrict__ off, int64_t U, int64_t n_frames,
-    srx_models_t md, F64Tables tb, double* __restrict__ out) {
+    srx_models_t md, F64Tables tb, int n_tiles, double* __restrict__ out) {
     constexpr int KQ = 4 * R;
     const int M = md.n_models, S = md.n_states, D = md.n_features;
     const int lane = threadIdx.x & 63, g = lane >> 4, ul = lane & 15;
-    const int tile = blockIdx.y;
-    const int64_t group = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (group * 16 >= U) return;
+    // Work item = (batch of 16 utterances, tile).  Models of at most 8 states: the tile runs
+    // fastest, so the waves that take the tiles of one batch sit next to each other (mostly in
+    // one workgroup) and walk the same frames at about the same time -- the batch's features
+    // come from memory once and from the cache for the other tiles (6 x 8 states: 3.87 -> 3.37
+    // ms per 65,536 x 200 frames, 24 x 4: 6.6 -> 5.6).  16-state models (a tile per model, 128
+    // transition registers per lane) measured half as fast again that way and keep the tile
+    // slowest.
+    const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t gp = ((U + 15) / 16 + 3) / 4 * 4;
+    const int tile = SP < 16 ? (int)(item % n_tiles) : (int)(item / gp);
+    const int64_t group = SP < 16 ? item / n_tiles : item % gp;
+    if (group * 16 >= U || tile >= n_tiles) return;
     const int64_t u = group * 16 + ul;
     const bool valid = u < U;
     const int64_t uc = valid ? u : U - 1;
@@ -456,9 +465,11 @@ template <int SP, int R>
 void launch(const double* X, const int64_t* off, int64_t U, int64_t n_frames, const srx_models_t& md,
             int n_tiles, F64Tables tb, double* out, hipStream_t st) {
     const int64_t groups = (U + 15) / 16;
-    const unsigned grid = (unsigned)((groups + 3) / 4);
-    hipLaunchKernelGGL((score_f64_kernel<SP, R>), dim3(grid, (unsigned)n_tiles), dim3(256), 0, st, X, off,
-                       U, n_frames, md, tb, out);
+    const int per_block = 4;
+    const int64_t items = SP < 16 ? groups * n_tiles : (groups + 3) / 4 * 4 * n_tiles;
+    const unsigned grid = (unsigned)((items + per_block - 1) / per_block);
+    hipLaunchKernelGGL((score_f64_kernel<SP, R>), dim3(grid), dim3(64 * per_block), 0, st, X, off,
+                       U, n_frames, md, tb, n_tiles, out);
 }
 
 }  // namespace
@@ -471,7 +482,7 @@ int srx_mfma_score_f64(srx_context* h, const void* X, const int64_t* off, int64_
     if (S > 16 || D > 48 || D < 1 || n_frames <= 0 || U <= 0) return SRX_EUNSUPPORTED;
     const int SP = S <= 4 ? 4 : (S <= 8 ? 8 : 16);
     const int n_tiles = (M * SP + 15) / 16;
-    if (n_tiles > 65535) return SRX_EUNSUPPORTED;
+    if ((int64_t)n_tiles * ((U + 15) / 16) > 0x7FFFFFFFll * 4) return SRX_EUNSUPPORTED;
     const int R = (D + 7) / 8;
     const int KQ = 4 * R;
     const size_t n_w = (size_t)n_tiles * 16 * KQ * 4, n_c = (size_t)n_tiles * 16;
