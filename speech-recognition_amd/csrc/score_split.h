@@ -81,6 +81,7 @@ struct SplitTables {
     const float* A;       // [M][S][S]
     const float* pi;      // [M][S]
     const int64_t* order; // scoring: visiting order of the utterances (a permutation), or NULL
+    int chunks = 1;       // slices of NT tiles that the bank is scored in (1 up to NT tiles)
 };
 
 __device__ __host__ inline unsigned bf16_rne(float f) {
@@ -149,10 +150,14 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(
     const float* __restrict__ X, const int64_t* __restrict__ off, int64_t U, int64_t n_frames,
     int M, int S, int D, SplitTables tb, double* __restrict__ out) {
     const int lane = threadIdx.x & 63, g = lane >> 4, ul = lane & 15;
-    const int64_t group = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // Work item = (batch of 16 utterances, slice of NT tiles), the slice running fastest: a bank
+    // of more than NT tiles reads its features once per slice, and with the slices of a batch
+    // in neighbouring waves the second reading comes from the cache.
+    const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int chunks = tb.chunks;
+    const int64_t group = chunks == 1 ? item : item / chunks;
     if (group * 16 >= U) return;
-    // banks of more than NT tiles: blockIdx.y takes tiles [tile0, tile0 + NT)
-    const int tile0 = blockIdx.y * NT;
+    const int tile0 = chunks == 1 ? 0 : (int)(item % chunks) * NT;
     // (with a visiting order -- the caller's way of putting utterances of similar length into one
     // batch -- lane ul takes entry group*16 + ul of it; the host passes one only when all of X
     // is within a descriptor's reach, since the utterances of a batch then lie anywhere)
@@ -495,8 +500,9 @@ template <int SP, int NT, int RQ, int H>
 void launch_split(const float* X, const int64_t* off, int64_t U, int64_t n_frames, int M, int S,
                   int D, int chunks, SplitTables tb, double* out, hipStream_t st) {
     const int64_t groups = (U + 15) / 16;
-    const unsigned grid = (unsigned)((groups + 3) / 4);
-    hipLaunchKernelGGL((score_split_kernel<SP, NT, RQ, H>), dim3(grid, (unsigned)chunks), dim3(256), 0,
+    const unsigned grid = (unsigned)((groups * chunks + 3) / 4);
+    tb.chunks = chunks;
+    hipLaunchKernelGGL((score_split_kernel<SP, NT, RQ, H>), dim3(grid), dim3(256), 0,
                        st, X, off, U, n_frames, M, S, D, tb, out);
 }
 
