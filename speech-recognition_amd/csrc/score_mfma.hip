@@ -240,7 +240,11 @@ __global__ __launch_bounds__(256) void emission_split_kernel(
     const float* __restrict__ X, int64_t n_frames, int C, int D, int NT, SplitTables tb,
     float* __restrict__ out) {
     const int lane = threadIdx.x & 63, g = lane >> 4, ul = lane & 15;
-    const int nt0 = blockIdx.y * NTC;
+    // (banks of more than NTC tiles: the slices of a group of 16 frames run in neighbouring waves,
+    // the slice index fastest, so that the frames come from memory once)
+    const int chunks = tb.chunks;
+    const int64_t wg = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int nt0 = (chunks == 1 ? 0 : (int)(wg % chunks)) * NTC;
     // (the feature axis is cut as in the scoring kernel: RQ blocks of 16 and, if H, a last
     // block of 8 whose operand carries hi and lo halves -- a 39-feature row is read in 160
     // bytes and takes 8 matrix instructions per tile instead of 9)
@@ -264,8 +268,8 @@ __global__ __launch_bounds__(256) void emission_split_kernel(
         for (int r = 0; r < 4; ++r) c0[nt][r] = on ? tb.cst[(nt0 + nt) * 16 + 4 * g + r] : 0.f;
     }
     const int64_t n_groups = (n_frames + 15) / 16;
-    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6) / chunks;
+    const int64_t wid = chunks == 1 ? wg : wg / chunks;
     const unsigned lane_off = (unsigned)ul * (unsigned)D * 4u + 16u * g;
     const unsigned half_off = (unsigned)ul * (unsigned)D * 4u + 64u * RQ + 8u * g;
     auto load = [&](int64_t grp, item_t& dst) {
@@ -612,7 +616,8 @@ int srx_mfma_emission(srx_context* h, const void* X, int64_t n_frames, const srx
     int64_t gx = (n_groups + 3) / 4;
     const int64_t cap = (int64_t)h->n_cu * 8;
     if (gx > cap) gx = cap;
-    const dim3 grid((unsigned)gx, (unsigned)chunks);
+    const dim3 grid((unsigned)(gx * chunks));
+    tb.chunks = chunks;
     const float* Xf = (const float*)X;
 #define SRX_CASE(ntc, rq, hh)                                                                \
     if (NTC == ntc && RQ == rq && H == hh) {                                                 \
