@@ -458,6 +458,36 @@ def test_scoring_banks_larger_than_three_tiles(sra, ctx, M, S, D):
     assert _rel(got, gen) < 2e-5
 
 
+@pytest.mark.parametrize("dtype,M,S,tol", [("float32", 12, 8, 2e-5), ("float32", 40, 3, 2e-5), ("float32", 5, 16, 2e-5),
+                                           ("float64", 9, 8, 1e-12), ("float64", 21, 4, 1e-12), ("float64", 3, 16, 1e-12)])
+def test_wide_banks_over_many_batches(sra, ctx, dtype, M, S, tol):
+    """Banks of several slices over many batches of 16 utterances (the slices of a batch are
+    taken by neighbouring waves; a last batch that is partly filled; lengths 0 and 1 among
+    them): every (utterance, model) score against the shape-generic kernels, and a sample of
+    them against the oracle."""
+    D = 39
+    rng = np.random.default_rng(3 * M + S)
+    prms = [ho.random_params(rng, S, D) for _ in range(M)]
+    U = 1003
+    lengths = rng.integers(1, 60, size=U)
+    lengths[[0, 500, 1002]] = 0
+    lengths[[1, 999]] = 1
+    X = rng.standard_normal((int(lengths.sum()), D))
+    bank = _bank(sra, ctx, prms)
+    data = sra.Ragged(ctx, X, lengths, dtype=dtype)
+    got = bank.score(data).cpu().numpy()
+    gen = bank.score(data, generic=True).cpu().numpy()
+    live = lengths > 0
+    assert got.shape == (U, M)
+    np.testing.assert_allclose(got[live], gen[live], rtol=tol, atol=tol)
+    np.testing.assert_array_equal(got[~live], gen[~live])
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    for u in (7, 640, 1001):
+        for m in (0, M // 2, M - 1):
+            ref = ho.score(prms[m], X[off[u]:off[u + 1]], loops=False)
+            assert abs(got[u, m] - ref) <= max(tol, 2e-5 if dtype == "float32" else 1e-11) * abs(ref)
+
+
 # ------------------------------------------------------------------ posteriors
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("dtype,tol", [("float64", 1e-10), ("float32", 2e-5)])
