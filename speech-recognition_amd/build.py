@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsrx.so")
-SOURCES = ["api.hip", "hmm_generic.hip", "score_mfma.hip", "score_split8.hip", "score_split4.hip", "score_split16.hip", "score_f64.hip", "estep_fused.hip", "viterbi_fused.hip", "mfcc.hip", "mfcc_fast.hip", "large_model.hip", "endpoint.hip", "pipeline.hip", "estep_wave.hip"]
+SOURCES = ["api.hip", "hmm_generic.hip", "score_mfma.hip", "score_split8.hip", "score_split4.hip", "score_split16.hip", "score_f64.hip", "estep_fused.hip", "viterbi_fused.hip", "mfcc.hip", "mfcc_fast.hip", "mfcc_wide.hip", "large_model.hip", "endpoint.hip", "pipeline.hip", "estep_wave.hip"]
 # Packed f32 vector instructions (what SLP vectorisation makes of adjacent adds and
 # multiplies) issue slower than the two plain ones beside matrix instructions.
 FILE_FLAGS = {"score_mfma.hip": ["-fno-slp-vectorize"], "score_split8.hip": ["-fno-slp-vectorize"],
@@ -19,7 +19,8 @@ FILE_FLAGS = {"score_mfma.hip": ["-fno-slp-vectorize"], "score_split8.hip": ["-f
               "viterbi_fused.hip": ["-fno-slp-vectorize"],
               # (the 512-point transform is written on plain registers: re-packed by the
               # vectoriser it needs a move per pair and runs 7 % slower)
-              "mfcc_fast.hip": ["-fno-slp-vectorize"]}
+              "mfcc_fast.hip": ["-fno-slp-vectorize"],
+              "mfcc_wide.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall",
          "-Wno-unused-function", "-fvisibility=default",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC]

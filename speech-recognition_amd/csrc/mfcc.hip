@@ -807,12 +807,21 @@ __global__ __launch_bounds__(256, FIN_WG) void finish_stream_kernel(
 // DCT and needs the largest log-mel value of the whole utterance: one workgroup per
 // utterance finds it over the stored log-mel rows, then each wave takes frames, raises
 // the row to (maximum - top_db) in its LDS strip and lanes k < n_ceps take DCT row k.
+// rowmax, rowmin (optional, together): the largest and smallest value of every row, left by a
+// kernel that wrote the rows AND the cepstra of the unclamped rows: only rows whose minimum
+// lies below the threshold are done again here (their log-mel row is not even read otherwise).
 template <typename T>
 __global__ __launch_bounds__(256) void topdb_dct_kernel(const T* __restrict__ logmel,
                                                         const int64_t* __restrict__ so, int64_t U,
                                                         MfccDev c, T top_db,
-                                                        const T* __restrict__ dct, T* __restrict__ cep) {
+                                                        const T* __restrict__ dct,
+                                                        const T* __restrict__ rowmax,
+                                                        const T* __restrict__ rowmin,
+                                                        T* __restrict__ cep) {
     __shared__ T red[256];
+    __shared__ T red_min[256];
+    constexpr int kMinRows = 1024;
+    __shared__ T s_min[kMinRows];
     __shared__ T strip[4][128];
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     // The lane's share of its DCT row (the split of dct_rows, summed in the same order)
@@ -835,15 +844,38 @@ __global__ __launch_bounds__(256) void topdb_dct_kernel(const T* __restrict__ lo
         const T* lm = logmel + row0 * c.n_mel;
         const int64_t cnt = Tu * c.n_mel;
         T m = lm[0];
-        for (int64_t i = threadIdx.x; i < cnt; i += blockDim.x) m = lm[i] > m ? lm[i] : m;
+        T mn = lm[0];
+        if (rowmax) {       // the rows' extrema are known: Tu values instead of Tu * n_mel
+            for (int64_t i = threadIdx.x; i < Tu; i += blockDim.x) {
+                const T hi = rowmax[row0 + i], lo = rowmin[row0 + i];
+                m = hi > m ? hi : m;
+                mn = lo < mn ? lo : mn;
+                if (i < kMinRows) s_min[i] = lo;
+            }
+        } else {
+            for (int64_t i = threadIdx.x; i < cnt; i += blockDim.x) m = lm[i] > m ? lm[i] : m;
+        }
         red[threadIdx.x] = m;
+        red_min[threadIdx.x] = mn;
         __syncthreads();
         for (int s = 128; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s && red[threadIdx.x + s] > red[threadIdx.x])
-                red[threadIdx.x] = red[threadIdx.x + s];
+            if ((int)threadIdx.x < s) {
+                if (red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s];
+                if (red_min[threadIdx.x + s] < red_min[threadIdx.x]) red_min[threadIdx.x] = red_min[threadIdx.x + s];
+            }
             __syncthreads();
         }
         const T thr = red[0] - top_db;
+        if (rowmax && !(red_min[0] < thr)) {    // nothing of this utterance lies below the threshold
+            __syncthreads();
+            continue;
+        }
+        // does row t need the clamp (always, when the rows' minima are not known)
+        auto need = [&](int64_t t) -> bool {
+            if (t >= Tu) return false;
+            if (!rowmax) return true;
+            return (t < kMinRows ? s_min[t] : rowmin[row0 + t]) < thr;
+        };
         if (held) {
             // the row of frame t + 4 is requested before the sums of frame t
             T nxt[2];
@@ -855,25 +887,33 @@ __global__ __launch_bounds__(256) void topdb_dct_kernel(const T* __restrict__ lo
                     nxt[j] = lm[tc * c.n_mel + (q < c.n_mel ? q : c.n_mel - 1)];
                 }
             };
-            request(wave);
+            bool cur = need(wave);
+            if (cur) request(wave);
             for (int64_t t = wave; t < Tu; t += 4) {
+                const bool nxt_needed = need(t + 4);
+                if (cur) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int q = lane + j * kWave;
-                    if (q < c.n_mel) strip[wave][q] = nxt[j] < thr ? thr : nxt[j];
+                    for (int j = 0; j < 2; ++j) {
+                        const int q = lane + j * kWave;
+                        if (q < c.n_mel) strip[wave][q] = nxt[j] < thr ? thr : nxt[j];
+                    }
                 }
-                request(t + 4);
-                wave_sync();
-                T acc = 0;
+                if (nxt_needed) request(t + 4);
+                if (cur) {
+                    wave_sync();
+                    T acc = 0;
 #pragma unroll
-                for (int i = 0; i < 32; ++i)
-                    if (i < held_n) acc += w[i] * strip[wave][part + i * parts];
-                for (int o = parts >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
-                if (k < c.n_ceps && part == 0) cep[(row0 + t) * c.n_ceps + k] = acc;
-                wave_sync();
+                    for (int i = 0; i < 32; ++i)
+                        if (i < held_n) acc += w[i] * strip[wave][part + i * parts];
+                    for (int o = parts >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
+                    if (k < c.n_ceps && part == 0) cep[(row0 + t) * c.n_ceps + k] = acc;
+                    wave_sync();
+                }
+                cur = nxt_needed;
             }
         } else {
             for (int64_t t = wave; t < Tu; t += 4) {
+                if (!need(t)) continue;
                 for (int q = lane; q < c.n_mel; q += kWave) {
                     const T v = lm[t * c.n_mel + q];
                     strip[wave][q] = v < thr ? thr : v;
@@ -1151,6 +1191,62 @@ static int plan_fill(srx_mfcc_plan* p, const srx_mfcc_cfg_t* cfg) {
             p->mm_nq = nq; p->mm_kk = kk; p->mm_groups = G; p->mm_ok = 1;
         }
     }
+    // ---- mel stage of the 2048-point kernel: every filter's bin range as whole quads of 4
+    // bins, filter-major, dealt to 64 lanes in equal runs; a lane's stretch of one filter ends
+    // in one partial sum (slot), and a filter's slots are consecutive.
+    p->wd_ok = 0;
+    if (N == 2048 && cfg->center && p->fast_ok && cfg->n_mel <= 128) {
+        struct Quad { int q, f, last; };
+        std::vector<Quad> quads;
+        for (int m = 0; m < cfg->n_mel; ++m) {
+            const int len = ptr[m + 1] - ptr[m];
+            const int q0 = starts[m] / 4, q1 = len > 0 ? (starts[m] + len - 1) / 4 : q0;
+            for (int q = q0; q <= q1; ++q) quads.push_back({q, m, q == q1});
+        }
+        // (quads per lane: a multiple of 12, the kernel requests its table entries in two
+        // alternating batches of 6)
+        const int lq = ((((int)quads.size() + 63) / 64 + 11) / 12) * 12;
+        std::vector<float> w4((size_t)lq * 64 * 4, 0.f);
+        std::vector<int32_t> meta((size_t)lq * 64, 0), pptr(cfg->n_mel + 1, 0);
+        int slot = -1, prev_f = -1, prev_lane = -1;
+        for (size_t i = 0; i < quads.size(); ++i) {
+            const int lane = (int)(i / lq), s = (int)(i % lq);
+            const Quad& qd = quads[i];
+            if (qd.f != prev_f || lane != prev_lane) ++slot;
+            if (qd.f != prev_f) pptr[qd.f] = slot;
+            prev_f = qd.f;
+            prev_lane = lane;
+            // the stretch ends with the filter or with the lane's run
+            const bool ends = qd.last || s == lq - 1;
+            meta[(size_t)s * 64 + lane] = qd.q | (slot << 16) | (ends ? (int32_t)0x80000000 : 0);
+            for (int q = ptr[qd.f]; q < ptr[qd.f + 1]; ++q)
+                if (bins[q] / 4 == qd.q) w4[((size_t)s * 64 + lane) * 4 + bins[q] % 4] = (float)w[q];
+        }
+        const int n_parts = slot + 1;
+        pptr[cfg->n_mel] = n_parts;
+        // runs shorter than lq (the tail of the last lanes): zero weights into the spare slot
+        for (size_t i = quads.size(); i < (size_t)lq * 64; ++i)
+            meta[(i % lq) * 64 + i / lq] = n_parts << 16;
+        if (n_parts + 1 <= 256 && lq >= 1) {
+            SRX_HIP(hipMalloc(&p->wd_w, sizeof(float) * w4.size()));
+            SRX_HIP(hipMemcpy(p->wd_w, w4.data(), sizeof(float) * w4.size(), hipMemcpyHostToDevice));
+            SRX_HIP(hipMalloc((void**)&p->wd_meta, sizeof(int32_t) * meta.size()));
+            SRX_HIP(hipMemcpy(p->wd_meta, meta.data(), sizeof(int32_t) * meta.size(), hipMemcpyHostToDevice));
+            SRX_HIP(hipMalloc((void**)&p->wd_ptr, sizeof(int32_t) * pptr.size()));
+            SRX_HIP(hipMemcpy(p->wd_ptr, pptr.data(), sizeof(int32_t) * pptr.size(), hipMemcpyHostToDevice));
+            std::vector<float> dpad((size_t)cfg->n_ceps * 128, 0.f);
+            for (int k = 0; k < cfg->n_ceps; ++k)
+                for (int n = 0; n < cfg->n_mel; ++n) {
+                    double v = sqrt(2.0 / cfg->n_mel) * cos(M_PI * k * (2 * n + 1) / (2.0 * cfg->n_mel));
+                    if (k == 0) v *= 1.0 / sqrt(2.0);
+                    dpad[(size_t)k * 128 + n] = (float)v;
+                }
+            SRX_HIP(hipMalloc(&p->wd_dct, sizeof(float) * dpad.size()));
+            SRX_HIP(hipMemcpy(p->wd_dct, dpad.data(), sizeof(float) * dpad.size(), hipMemcpyHostToDevice));
+            p->wd_lq = lq;
+            p->wd_ok = 1;
+        }
+    }
     std::vector<float> twf(2 * (size_t)N);
     for (int k = 0; k < N; ++k) {
         twf[2 * k] = (float)cos(2.0 * M_PI * k / N);
@@ -1219,6 +1315,10 @@ int srx_mfcc_plan_destroy(srx_mfcc_plan_t p) {
     (void)hipFree(p->mm_w);
     (void)hipFree(p->mm_dct);
     (void)hipFree(p->mm_meta);
+    (void)hipFree(p->wd_w);
+    (void)hipFree(p->wd_meta);
+    (void)hipFree(p->wd_ptr);
+    (void)hipFree(p->wd_dct);
     delete p;
     return SRX_OK;
 }
@@ -1304,15 +1404,31 @@ int srx_mfcc_batch(srx_handle_t h, srx_mfcc_plan_t p, const void* audio, int dty
         if (d.logmel)
             hipLaunchKernelGGL(topdb_dct_kernel<double>, dim3((unsigned)grid2), dim3(256), 0, st,
                                (const double*)d.logmel, sample_offsets, n_utts, d, c.top_db,
-                               (const double*)p->dct[idx], (double*)cep);
+                               (const double*)p->dct[idx], (const double*)nullptr, (const double*)nullptr,
+                               (double*)cep);
         if (!launch_finish_stream<double>(h, cep, sample_offsets, frame_offsets, n_utts, d, c, out_feats, st))
             hipLaunchKernelGGL(finish_kernel<double>, dim3((unsigned)grid2), dim3(256), fin_lds, st,
                                (const double*)cep, sample_offsets, frame_offsets, n_utts, d,
                                c.delta_order, c.delta_n, c.zscore, fin_elems, (double*)out_feats);
     } else {
-        rc = h->exact_f32 ? SRX_EUNSUPPORTED
-                          : srx_mfcc_fast_cepstra(h, p, (const float*)audio, sample_offsets, n_utts,
-                                                  n_samples, (float*)cep, st);
+        // centred 2048-point frames: cepstra of the unclamped log-mel rows from the register-FFT
+        // kernel; with top_db, the rows that reach below the threshold are done again
+        float *rowmax = nullptr, *rowmin = nullptr;
+        void* wide_logmel = nullptr;
+        rc = SRX_EUNSUPPORTED;
+        if (!h->exact_f32 && p->wd_ok) {
+            if (c.top_db > 0.0) {
+                rc = srx_ws_ensure(h, WS_LOGLIK, esz * (size_t)rows * c.n_mel, &wide_logmel);
+                if (rc) return rc;
+            }
+            rc = srx_mfcc_wide_cepstra(h, p, (const float*)audio, sample_offsets, n_utts, n_samples,
+                                       c.top_db > 0.0 ? (float*)wide_logmel : nullptr, (float*)cep,
+                                       &rowmax, &rowmin, st);
+            if (rc == SRX_OK) d.logmel = c.top_db > 0.0 ? wide_logmel : nullptr;
+        }
+        if (rc == SRX_EUNSUPPORTED && !h->exact_f32)
+            rc = srx_mfcc_fast_cepstra(h, p, (const float*)audio, sample_offsets, n_utts, n_samples,
+                                       (float*)cep, st);
         if (rc == SRX_EUNSUPPORTED)
             hipLaunchKernelGGL(cepstra_kernel<float>, dim3((unsigned)grid), dim3(waves * kWave),
                                per_wave * waves, st, (const float*)audio, sample_offsets, n_utts,
@@ -1324,7 +1440,8 @@ int srx_mfcc_batch(srx_handle_t h, srx_mfcc_plan_t p, const void* audio, int dty
         if (d.logmel)
             hipLaunchKernelGGL(topdb_dct_kernel<float>, dim3((unsigned)grid2), dim3(256), 0, st,
                                (const float*)d.logmel, sample_offsets, n_utts, d, (float)c.top_db,
-                               (const float*)p->dct[idx], (float*)cep);
+                               (const float*)p->dct[idx], (const float*)rowmax, (const float*)rowmin,
+                               (float*)cep);
         if (!launch_finish_stream<float>(h, cep, sample_offsets, frame_offsets, n_utts, d, c, out_feats, st))
             hipLaunchKernelGGL(finish_kernel<float>, dim3((unsigned)grid2), dim3(256), fin_lds, st,
                                (const float*)cep, sample_offsets, frame_offsets, n_utts, d,

@@ -52,6 +52,12 @@ struct srx_mfcc_plan {
     void* mm_dct;          // [64][mm_kk] DCT coefficients per lane
     int32_t* mm_meta;      // [16] first bin of a block, [16] first block and [16] block count of a filter group
     int mm_nq, mm_kk, mm_groups, mm_ok;
+    // mel stage of the 2048-point register-FFT kernel (see mfcc_wide.hip)
+    void* wd_w;            // [wd_lq][64][4] filter weights of a quad of bins
+    int32_t* wd_meta;      // [wd_lq][64] quad index | partial-sum slot << 16 | last quad of its filter << 31
+    int32_t* wd_ptr;       // [n_mel + 1] partial sums of a filter
+    void* wd_dct;          // [n_ceps][128] DCT-II rows, zero past n_mel
+    int wd_lq, wd_ok;
 };
 
 void srx_set_error(const char* fmt, ...);
@@ -191,6 +197,14 @@ int srx_fused_posteriors(srx_context* h, const void* X, const int64_t* off, int6
 int srx_fused_viterbi(srx_context* h, const void* X, const int64_t* off, int64_t U, int64_t n_frames,
                       const int32_t* utt_model, const srx_models_t* md, const float* logA,
                       const float* logpi, int32_t* path, double* lp, hipStream_t st);
+
+// Implemented in mfcc_wide.hip (float32, centred 2048-point frames): log-mel rows
+// [rows, n_mel] and the cepstra of the unclamped rows [rows, n_ceps] on the virtual sample axis
+// and, in the WS_MISC slot, each row's largest and smallest log-mel value; else
+// SRX_EUNSUPPORTED.
+int srx_mfcc_wide_cepstra(srx_context* h, srx_mfcc_plan* plan, const float* audio,
+                          const int64_t* sample_offsets, int64_t U, int64_t total, float* logmel,
+                          float* cep, float** rowmax_out, float** rowmin_out, hipStream_t st);
 
 // Implemented in mfcc_fast.hip (float32, nfft 512 / 1024), else SRX_EUNSUPPORTED.
 int srx_mfcc_fast_cepstra(srx_context* h, srx_mfcc_plan* plan, const float* audio,

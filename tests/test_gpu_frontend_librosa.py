@@ -169,3 +169,55 @@ def test_librosa_conventions_random_configurations(sra, dtype, tol):
                 assert err <= (1e-6 if dtype == "float64" else 2e-2), (tag, k, err)
             else:
                 assert np.abs(got - ref).max() <= tol * np.abs(ref).max(), (tag, k)
+
+
+@pytest.mark.parametrize("pad_mode", ["constant", "reflect"])
+@pytest.mark.parametrize("n_mels,n_mfcc,top_db", [(128, 13, 80.0), (128, 20, 80.0), (64, 32, 0.0),
+                                                  (40, 13, 30.0), (8, 4, 80.0)])
+def test_register_transform_at_2048_points_equals_generic_kernels(sra, pad_mode, n_mels, n_mfcc, top_db):
+    """The 2048-point register-FFT kernel (float32, centred frames) against the shape-generic
+    kernels on the same ragged batch -- 600 utterances, so that workgroups meet utterance ends
+    in both frames of a wave, rows without a frame, one-sample and empty utterances (zero
+    padding only), digital silence (floor and clamp) and loud clicks (every other row of the
+    utterance clamps) -- and against the oracle on the first few.  Cepstral counts on both
+    sides of what the kernel keeps in LDS, filter counts that make a filter wider than a
+    lane's run, with and without the clamp."""
+    rng = np.random.default_rng(23)
+    lo = 1025 if pad_mode == "reflect" else 0
+    lens = [int(v) for v in rng.integers(lo, 9000, size=600)]
+    lens[5:9] = [2048, 2047, 4096, 512 * 7 + 1024]
+    if pad_mode == "constant":
+        lens[20:23] = [0, 1, 3]
+    sigs = []
+    for k, n in enumerate(lens):
+        s = (0.05 * rng.standard_normal(n)).astype(np.float32)
+        if n > 4000 and k % 3 == 0:
+            s[1000:3500] = 0.0
+        if n > 4000 and k % 7 == 0:
+            s[n // 2] = 30.0
+        sigs.append(s)
+    kw = dict(n_fft=2048, hop_length=512, n_mels=n_mels, pad_mode=pad_mode, top_db=top_db)
+    ctx = sra.Context.default()
+    f, ln = sra.mfcc.librosa_mfcc_batch(sigs, 22050, n_mfcc, dtype="float32", **kw)
+    ctx.set_exact_f32(True)          # the shape-generic kernels
+    try:
+        g, ln_g = sra.mfcc.librosa_mfcc_batch(sigs, 22050, n_mfcc, dtype="float32", **kw)
+    finally:
+        ctx.set_exact_f32(False)
+    assert list(ln) == list(ln_g) and f.shape == g.shape
+    assert np.isfinite(f).all()
+    off = np.concatenate([[0], np.cumsum(ln)])
+    worst = 0.0
+    for k in range(len(sigs)):
+        if ln[k]:
+            worst = max(worst, _row_rms_error(f[off[k]:off[k + 1]], g[off[k]:off[k + 1]]))
+    cfg = mo.LibrosaConfig(sample_rate=22050, n_mfcc=n_mfcc, n_fft=2048, hop_length=512, n_mels=n_mels,
+                           pad_mode=pad_mode, top_db=top_db)
+    worst_o = 0.0
+    for k in list(range(12)) + [20, 21, 22]:
+        ref = mo.librosa_mfcc(sigs[k].astype(np.float64), cfg)
+        assert ref.shape == (ln[k], n_mfcc)
+        if ref.size:
+            worst_o = max(worst_o, _row_rms_error(f[off[k]:off[k + 1]], ref))
+    print(f"2048-point register kernel {pad_mode} {n_mels}/{n_mfcc}/{top_db}: vs generic {worst:.2e}, vs oracle {worst_o:.2e}")
+    assert worst <= 2e-4 and worst_o <= 2e-4
