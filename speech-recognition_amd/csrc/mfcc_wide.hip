@@ -139,51 +139,52 @@ __global__ __launch_bounds__(32 * kFB, 2) void cepstra_wide_kernel(
         return r < n_rows ? v : int4{0, 0, 0, 0};
     };
     // The samples of one frame.  A frame that lies inside its utterance is 32 contiguous loads
-    // per lane; one that reaches over an end (the first and last two or three of an utterance)
-    // takes every sample from where the padding rule puts it.
-    auto fetch = [&](const int4& m, float (&xr)[2 * kP]) {
-        const bool valid = m.w != 0;
+    // per lane, requested a step ahead; any other group (no frame, or a frame that reaches over
+    // an end of its utterance) requests the buffer's first 2048 samples instead, so that the
+    // requests are the same instructions in every step and land in the registers they are
+    // used from.
+    auto interior_of = [&](const int4& m) {
         const int rel = m.x - m.y;                  // first point, relative to the utterance
-        const bool interior = valid && rel >= 0 && rel + kN <= m.z;
-        const bool edge = valid && !interior;
-        if (__ballot(edge) != 0) {
-            // some frame of the wave reaches over an end of its utterance: both frames take
-            // every sample from where the padding rule puts it (reflection about the first and
-            // the last sample, then a clamp for frames that reach further than one utterance
-            // length; zeros outside otherwise).  A group without a frame reads sample 0.
-            const int n = m.z;
-            const float* base = audio + m.y;
-            if constexpr (CENTER == 2) {
+        return m.w != 0 && rel >= 0 && rel + kN <= m.z;
+    };
+    auto fetch = [&](const int4& m, float (&xr)[2 * kP]) {
+        const float* p = audio + (interior_of(m) ? (int64_t)m.x : 0) + 2 * j;
 #pragma unroll
-                for (int i = 0; i < 2 * kP; ++i) {
-                    int q = rel + 64 * (i >> 1) + 2 * j + (i & 1);
-                    q = q < 0 ? -q : q;
-                    const int r = 2 * (n - 1) - q;
-                    q = r < q ? r : q;
-                    q = q < 0 ? 0 : q;
-                    xr[i] = base[q];
-                    // (eight at a time: the addresses of all 64 do not fit the registers)
-                    if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
+        for (int n1 = 0; n1 < kP; ++n1) {
+            const f2u v = *(const f2u*)(p + 64 * n1);
+            xr[2 * n1] = v.x;
+            xr[2 * n1 + 1] = v.y;
+        }
+    };
+    // A frame that reaches over an end (the first and last two or three of an utterance) takes
+    // every sample from where the padding rule puts it -- reflection about the first and the
+    // last sample, then a clamp for frames that reach further than one utterance length; zeros
+    // outside otherwise -- at the start of its own step; the wave's other frame comes along.
+    // A group without a frame reads sample 0.
+    auto gather = [&](const int4& m, float (&xr)[2 * kP]) {
+        const int rel = m.x - m.y;
+        const int n = m.z;
+        const float* base = audio + m.y;
+        if constexpr (CENTER == 2) {
 #pragma unroll
-                for (int i = 0; i < 2 * kP; ++i) {
-                    const int q = rel + 64 * (i >> 1) + 2 * j + (i & 1);
-                    const bool in = (unsigned)q < (unsigned)n;
-                    const float v = base[in ? q : 0];
-                    xr[i] = in ? v : 0.f;
-                    if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int i = 0; i < 2 * kP; ++i) {
+                int q = rel + 64 * (i >> 1) + 2 * j + (i & 1);
+                q = q < 0 ? -q : q;
+                const int r = 2 * (n - 1) - q;
+                q = r < q ? r : q;
+                q = q < 0 ? 0 : q;
+                xr[i] = base[q];
+                // (eight at a time: the addresses of all 64 do not fit the registers)
+                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
-        } else if (__ballot(interior) != 0) {
-            // (a group without a frame reads the buffer's first samples -- there are 2048 of
-            // them, or no frame would be interior -- and uses nothing of them)
-            const float* p = audio + (interior ? (int64_t)m.x : 0) + 2 * j;
+        } else {
 #pragma unroll
-            for (int n1 = 0; n1 < kP; ++n1) {
-                const f2u v = *(const f2u*)(p + 64 * n1);
-                xr[2 * n1] = v.x;
-                xr[2 * n1 + 1] = v.y;
+            for (int i = 0; i < 2 * kP; ++i) {
+                const int q = rel + 64 * (i >> 1) + 2 * j + (i & 1);
+                const bool in = (unsigned)q < (unsigned)n;
+                const float v = base[in ? q : 0];
+                xr[i] = in ? v : 0.f;
+                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(32 * kFB, 2) void cepstra_wide_kernel(
     auto transform = [&](const int4& m, int64_t row, float (&xc)[2 * kP], const int4& m_next) {
         const bool have = m.w != 0;
         const bool any = __ballot(have) != 0;
+        if (__ballot(have && !interior_of(m)) != 0) gather(m, xc);
         // ---- 1. window, bit-reversed register order, 32-point FFT over n1
         cpx z1[kP];
 #pragma unroll
@@ -434,7 +436,9 @@ int srx_mfcc_wide_cepstra(srx_context* h, srx_mfcc_plan* p, const float* audio, 
                           float** rowmin_out, hipStream_t st) {
     const srx_mfcc_cfg_t& c = p->cfg;
     *rowmax_out = *rowmin_out = nullptr;
-    if (!p->wd_ok || c.nfft != kN || !c.center || c.hop < 2) return SRX_EUNSUPPORTED;
+    // (total >= 2048: the kernel requests the buffer's first 2048 samples where a step has no
+    // frame that lies inside its utterance)
+    if (!p->wd_ok || c.nfft != kN || !c.center || c.hop < 2 || total < kN) return SRX_EUNSUPPORTED;
     const int64_t v_total = total + U * (int64_t)c.hop;
     if (v_total >= 0x7FFFF000ll) return SRX_EUNSUPPORTED;
     WideDev d;
