@@ -1100,6 +1100,8 @@ static int plan_fill(srx_mfcc_plan* p, const srx_mfcc_cfg_t* cfg) {
         for (int q = q0; q < q1; ++q)
             if (bins[q] != starts[m] + (q - q0)) p->fast_ok = 0;
     }
+    // (Both register-transform kernels leave |2 X|^2 in their power bins: the factor 1/4, and 1/N
+    // where the spectrum is divided by N, both powers of two, are part of these tables' weights.)
     // ---- block tables of the fast kernel's mel and DCT stages.  A 4x4x1 matrix
     // instruction is 16 independent 4x4 outer products, one per group of 4 lanes:
     // a block = 4 consecutive filters x a range of bins (first bin a multiple of 4,
@@ -1166,7 +1168,7 @@ static int plan_fill(srx_mfcc_plan* p, const srx_mfcc_cfg_t* cfg) {
                     const int bin = bins[q];
                     if (bin < blk[b].lo || bin >= blk[b].hi) continue;
                     const int rel = bin - k0;
-                    w4[((size_t)(rel / 4) * 64 + 4 * b + i) * 4 + rel % 4] = (float)w[q];
+                    w4[((size_t)(rel / 4) * 64 + 4 * b + i) * 4 + rel % 4] = (float)w[q] * (0.25f / (float)N);
                 }
             }
         }
@@ -1220,7 +1222,8 @@ static int plan_fill(srx_mfcc_plan* p, const srx_mfcc_cfg_t* cfg) {
             const bool ends = qd.last || s == lq - 1;
             meta[(size_t)s * 64 + lane] = qd.q | (slot << 16) | (ends ? (int32_t)0x80000000 : 0);
             for (int q = ptr[qd.f]; q < ptr[qd.f + 1]; ++q)
-                if (bins[q] / 4 == qd.q) w4[((size_t)s * 64 + lane) * 4 + bins[q] % 4] = (float)w[q];
+                if (bins[q] / 4 == qd.q)
+                    w4[((size_t)s * 64 + lane) * 4 + bins[q] % 4] = (float)w[q] * (cfg->power_norm ? 0.25f : 0.25f / (float)N);
         }
         const int n_parts = slot + 1;
         pptr[cfg->n_mel] = n_parts;

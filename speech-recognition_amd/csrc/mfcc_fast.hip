@@ -253,7 +253,6 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
             *(f32x4*)(slots + j * LT + 2 * u) = f32x4{a.x, a.y, b.x, b.y};
         }
         wave_sync();
-        const float quarter_inv_n = 0.25f / (float)N;
         cpx zks[P / 2], zcs[P / 2];
         {
             const int jp = (16 - j) & 15;
@@ -272,12 +271,12 @@ __global__ __launch_bounds__(16 * frames_per_block<P>(), (kWgPerCu<P> * 16 * fra
         for (int mm = 0; mm < P / 2; ++mm) {
             const int k = j + 16 * mm;
             // with E = (Z[k] + conj Z[H-k]) / 2 and O = -i (Z[k] - conj Z[H-k]) / 2:
-            // X[k] = E + W^k O ;  X[H-k] = conj(E - W^k O).  The halves are left out
-            // until the end (|2X|^2 / 4).
-            power_pair(zks[mm], zcs[mm], s_tw[k], quarter_inv_n, pw[k], pw[H - k]);
+            // X[k] = E + W^k O ;  X[H-k] = conj(E - W^k O).  The halves are left out: pw holds
+            // |2X|^2, and the factor 1 / (4 N), a power of two, sits in the mel weights.
+            power_pair(zks[mm], zcs[mm], s_tw[k], 1.f, pw[k], pw[H - k]);
         }
         if (j == 0) {   // k = H/2 is its own partner: E = (zr, 0), O = (zi, 0), W^(H/2) = -i
-            pw[H / 2] = (zh.x * zh.x + zh.y * zh.y) * (4.f * quarter_inv_n);
+            pw[H / 2] = (zh.x * zh.x + zh.y * zh.y) * 4.f;
         }
         if (j < 3) pw[H + 1 + j] = 0.f;           // padding that meets zero weights: keep it finite
         wave_sync();

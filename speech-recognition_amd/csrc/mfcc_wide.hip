@@ -10,7 +10,8 @@
 //      32-point FFT over j: it ends up with Z[k1 + 32 m], m < 32;
 //   4. the real-input spectrum is unpacked from Z[k], Z[H-k] -- a lane's own lower half and the
 //      upper half of one partner lane, which is all that goes through LDS -- and squared into
-//      the power spectrum pw[H+1] in the frame's LDS tile;
+//      pw[H+1] = |2 X|^2 in the frame's LDS tile (the factor 1/4, or 1/(4 N) for a spectrum
+//      divided by N, is a power of two and sits in the mel weights);
 //   5. mel energies: the filters' bin ranges, cut into quads of 4 bins (filter-major), are dealt
 //      to the wave's 64 lanes in equal runs; a lane walks its run for both frames of the wave,
 //      one 16-byte LDS read per frame and quad, and leaves one partial sum per (filter, lane)
@@ -52,7 +53,7 @@ constexpr int kDctLdsRows = 15;         // rows that fit beside 16 frames in 160
 
 struct WideDev {
     int hop, n_mel, center;
-    float power_scale, log_mult, log_floor;
+    float log_mult, log_floor;
     const float* window;        // [2048] (the window sits in the middle of the transform)
     const float2* tw;           // [2048] exp(-2 pi i k / 2048)
     int lq;                     // quads per lane
@@ -206,7 +207,6 @@ __global__ __launch_bounds__(32 * kFB, 2) void cepstra_wide_kernel(
             w[u] = *(const f32x4*)((const char*)c.w + (size_t)ow + u * 1024);
         }
     };
-    const float quarter_scale = 0.25f * c.power_scale;
     // log_mult * log10(2) as a float and the part of it the float misses
     const double scale_d = (double)c.log_mult * 0.30102999566398120;
     const float log2_scale = (float)scale_d, log2_scale_lo = (float)(scale_d - (double)log2_scale);
@@ -270,12 +270,12 @@ __global__ __launch_bounds__(32 * kFB, 2) void cepstra_wide_kernel(
 #pragma unroll
         for (int mm = 0; mm < kP / 2; ++mm) {
             const int k = j + kP * mm;
-            power_pair(z2[mm], zcs[mm], s_tw[k], quarter_scale, pw[k], pw[kH - k]);
+            power_pair(z2[mm], zcs[mm], s_tw[k], 1.f, pw[k], pw[kH - k]);
         }
         int32_t mt0[kMelBatch];
         f32x4 w0[kMelBatch];
         mel_batch(0, mt0, w0);                    // (the mel stage's first table entries)
-        if (j == 0) pw[kH / 2] = (zh.x * zh.x + zh.y * zh.y) * (4.f * quarter_scale);
+        if (j == 0) pw[kH / 2] = (zh.x * zh.x + zh.y * zh.y) * 4.f;
         if (j < 3) pw[kH + 1 + j] = 0.f;          // padding that meets zero weights: keep it finite
         wave_sync();
         // ---- 5. mel energies: the lane's run of quads, for both frames of the wave
@@ -443,7 +443,6 @@ int srx_mfcc_wide_cepstra(srx_context* h, srx_mfcc_plan* p, const float* audio, 
     if (v_total >= 0x7FFFF000ll) return SRX_EUNSUPPORTED;
     WideDev d;
     d.hop = c.hop; d.n_mel = c.n_mel; d.center = c.center;
-    d.power_scale = c.power_norm ? 1.f : 1.f / (float)kN;
     d.log_mult = (float)c.log_mult;
     d.log_floor = (float)c.log_floor;
     d.window = (const float*)p->window[0];

@@ -99,13 +99,24 @@ def _check_estep_and_mstep(sra, ctx, hmm_golden, case, dtype, generic):
     np.testing.assert_allclose(mu[0], g[p + "m_mu"], rtol=pt, atol=pt)
     np.testing.assert_allclose(cv[0], g[p + "m_var"], rtol=pt, atol=pt)
     # second iteration from the re-estimated model
+    own = ho.Params(sp[0], A[0], mu[0], cv[0])      # the device's own parameters after iteration 1
     stats2 = bank.estep(data, generic=generic)
     lp2 = float(stats2[0, 1].item())
     assert abs(lp2 - float(g[p + "logprob2"])) < (1e-9 if dtype == "float64" else 1e-5) * abs(lp2)
     bank.mstep(stats2, mode="full")
     sp, A, mu, cv = bank.params_host()
+    # against the reference's trajectory (its iteration 2 started from ITS iteration 1) ...
     np.testing.assert_allclose(mu[0], g[p + "m2_mu"], rtol=pt * 5, atol=pt * 5)
     np.testing.assert_allclose(cv[0], g[p + "m2_var"], rtol=pt * 5, atol=pt * 5)
+    # ... and the per-iteration bar proper: one oracle iteration from the parameters this
+    # iteration started from
+    st_o, lps_o = ho.estep(own, g[p + "X"], g[p + "lengths"], loops=False)
+    q = ho.mstep_full(own, st_o)
+    assert abs(lp2 - lps_o.sum()) < (1e-9 if dtype == "float64" else 1e-5) * abs(lp2)
+    np.testing.assert_allclose(sp[0], q.pi, rtol=pt, atol=1e-6 if dtype == "float32" else 1e-13)
+    np.testing.assert_allclose(A[0], q.A, rtol=pt, atol=1e-6 if dtype == "float32" else 1e-13)
+    np.testing.assert_allclose(mu[0], q.means, rtol=pt, atol=pt)
+    np.testing.assert_allclose(cv[0], q.covars, rtol=pt, atol=pt)
 
 
 @pytest.mark.parametrize("case", CASES)
