@@ -4,8 +4,10 @@
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define M_BF16(acc) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define M_BF16K16(acc) asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a4), "v"(b4))
 #define M_F32(acc) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y))
 #define M_F32S(acc) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y))
 #define M_F64(acc) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(d##acc) : "v"(dx), "v"(dy))
@@ -18,6 +20,8 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
     f64x4 dc0 = {0, 0, 0, 0}, dc1 = dc0, dc2 = dc0, dc3 = dc0;
     bf16x8 a, b;
     for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(threadIdx.x * 1e-3f); b[i] = (__bf16)(i * 1e-3f); }
+    bf16x4 a4, b4;
+    for (int i = 0; i < 4; ++i) { a4[i] = a[i]; b4[i] = b[i]; }
     float x = threadIdx.x * 1e-3f, y = 1e-3f;
     double dx = x, dy = y;
     for (int it = 0; it < iters; ++it) {
@@ -25,6 +29,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
         if (MODE == 1) { REP8(M_F32) }
         if (MODE == 2) { REP8(M_F32S) }
         if (MODE == 3) { REP8(M_F64) }
+        if (MODE == 4) { REP8(M_BF16K16) }
     }
     out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3] + (float)(dc0[0] + dc1[1] + dc2[2] + dc3[3]);
 }
@@ -53,5 +58,6 @@ int main() {
     run<1>("v_mfma_f32_16x16x4_f32", out);
     run<2>("v_mfma_f32_4x4x1_16b_f32", out);
     run<3>("v_mfma_f64_16x16x4_f64", out);
+    run<4>("v_mfma_f32_16x16x16_bf16", out);
     return 0;
 }
