@@ -100,7 +100,8 @@ __global__ __launch_bounds__(32 * kFB, 2) void cepstra_wide_kernel(
     float* s_win = (float*)(s_tw + kH / 2);           // [N]
     v2f* s_tw2 = (v2f*)(s_win + kN);                  // [32][32]: W_H^(j k1)
     float* s_frames = (float*)(s_tw2 + kP * kP);
-    // the DCT rows, when they fit what the frames leave of the CU's LDS (n_ceps <= 16)
+    // the DCT rows, when they fit what the frames leave of the CU's LDS (n_ceps <= 15; from
+    // global memory otherwise)
     float* s_dct = s_frames + (size_t)kFB * kPerFrame;
     const bool dct_lds = c.n_ceps <= kDctLdsRows;
     if (dct_lds)
