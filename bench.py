@@ -513,6 +513,9 @@ def main():
         extra["mfcc_librosa"] = {"frames_per_s": lib_frames * world / dtl, "frames_per_gpu": lib_frames,
                                  "ms": dtl * 1e3,
                                  "hbm_frac": lib_frames * (512 * 4 + 13 * 4) / dtl / 1e9 / HBM_PEAK_GBS,
+                                 "bound": "vector ALU issue (1879 vector + 190 LDS instructions per wave-step of 2 "
+                                          "frames; the two waves of a SIMD keep its vector pipe busy 0.81 of the "
+                                          "kernel's time by the shader counters); HBM line shown for reference",
                                  "config": "librosa.feature.mfcc conventions: 22.05 kHz, centred 2048-pt frames "
                                            "every 512 samples, Hann, 128 Slaney mel, 10 log10, top_db 80, 13 MFCC, "
                                            "z-score (2048-point transform in registers, 32 lanes per frame)"}
