@@ -87,14 +87,16 @@ __global__ __launch_bounds__(256) void row_meta_kernel(const int64_t* __restrict
     }
 }
 
-// CENTER: the padding rule (1 zeros, 2 reflection), a compile-time constant
-// cpx: plain (re, im) registers measured faster than packed pairs here (1.86 against 1.94 ms per
-// 770,048 frames, whole front-end pass)
-template <typename cpx, int CENTER>
+// CENTER: the padding rule (1 zeros, 2 reflection); PARTS: lanes that share a DCT coefficient
+// (2 up to 16 cepstra, else 1) -- compile-time constants.
+// (Plain (re, im) registers measured faster than packed pairs here: 1.86 against 1.94 ms per
+// 770,048 frames, whole front-end pass.)
+template <int CENTER, int PARTS>
 __global__ __launch_bounds__(32 * kFB, 2) void cepstra_wide_kernel(
     const float* __restrict__ audio, const int4* __restrict__ row_meta, int64_t n_rows, WideDev c,
     float* __restrict__ logmel, float* __restrict__ rowmax, float* __restrict__ rowmin,
     float* __restrict__ cep) {
+    typedef cf cpx;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     v2f* s_tw = (v2f*)smem_raw;                       // [H/2]: exp(-2 pi i k / N)
     float* s_win = (float*)(s_tw + kH / 2);           // [N]
@@ -212,23 +214,31 @@ __global__ __launch_bounds__(32 * kFB, 2) void cepstra_wide_kernel(
     const double scale_d = (double)c.log_mult * 0.30102999566398120;
     const float log2_scale = (float)scale_d, log2_scale_lo = (float)(scale_d - (double)log2_scale);
 
-    // one step: the frames whose samples are in xc (record m, row `row`); the samples are dead
-    // once the window has been applied: the next step's are requested into the same registers
-    // right there, a whole step before they are used
-    auto transform = [&](const int4& m, int64_t row, float (&xc)[2 * kP], const int4& m_next) {
-        const bool have = m.w != 0;
-        const bool any = __ballot(have) != 0;
-        if (__ballot(have && !interior_of(m)) != 0) gather(m, xc);
-        // ---- 1. window, bit-reversed register order, 32-point FFT over n1
-        cpx z1[kP];
+    // First register stage of a step: the frames whose samples are in xc (record m) are windowed
+    // into z1 (bit-reversed order) and transformed over n1.  The samples are dead once the
+    // window has been applied: the step after's are requested into the same registers right
+    // there, a whole step before they are used.
+    auto head_window = [&](float (&xc)[2 * kP], cpx (&z1)[kP]) {
 #pragma unroll
         for (int n1 = 0; n1 < kP; ++n1) {
             const float2 wv = *(const float2*)(s_win + 64 * n1 + 2 * j);
             z1[brev(n1, 5)] = cpx{xc[2 * n1] * wv.x, xc[2 * n1 + 1] * wv.y};
         }
+    };
+    auto head = [&](const int4& m, float (&xc)[2 * kP], const int4& m_next, cpx (&z1)[kP]) {
+        if (__ballot(m.w != 0 && !interior_of(m)) != 0) gather(m, xc);
+        head_window(xc, z1);
         fetch(m_next, xc);
-        if (!any) return;
         fft_regs<kP>(z1);
+    };
+    // The rest of a step (record m, row `row`, first stage in z1); at its end the first register
+    // stage of the NEXT step (records m_n, then m_nn): the compiler may then start that stage's
+    // arithmetic under the last LDS reads of this step.  (Interleaving the DCT's reads with the
+    // next transform's stages by hand needs ~26 registers more than there are: 2.5 ms with the
+    // spills against 1.73.)
+    auto transform = [&](const int4& m, int64_t row, cpx (&z1)[kP], float (&xc)[2 * kP], const int4& m_n,
+                         const int4& m_nn) {
+        const bool have = m.w != 0;
         // ---- 2. twiddle W_H^(j k1) and 3. transpose through LDS: Y[k1][j]
 #pragma unroll
         for (int k1 = 0; k1 < kP; ++k1) Y[k1 * (kP + 1) + j] = twiddled(s_tw2[k1 * kP + j], z1[k1], k1 == 0);
@@ -390,19 +400,24 @@ __global__ __launch_bounds__(32 * kFB, 2) void cepstra_wide_kernel(
         // ---- 6. DCT-II of the row as it is: lane (frame fs, coefficient k, part) sums every
         // filter of its part of the row (all lanes of a frame read the same LDS words)
         {
-            const int kp = c.n_ceps <= 16 ? 16 : 32, parts = 32 / kp;       // (n_ceps <= 32)
-            const int k = j / parts, part = j % parts, cnt = kMelPad / parts;
+            constexpr int cnt = kMelPad / PARTS;
+            const int k = j / PARTS, part = j % PARTS;
             const float* lm = (fs ? lmB : lmA) + part * cnt;
             const float* dr = (dct_lds ? s_dct + (k < c.n_ceps ? k : 0) * kDctStride
                                        : c.dct + (size_t)(k < c.n_ceps ? k : 0) * kMelPad) + part * cnt;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            for (int q = 0; q < cnt; q += 32) {
-                f32x4 dv[8], lv[8];
+            // (32 filters at a time: 8 + 8 LDS reads, then 32 multiply-adds.  The scheduling
+            // barriers keep the compiler from requesting everything first, which would not fit
+            // the registers next to z1 and the samples.)
+            f32x4 dv[8], lv[8];
+            auto request = [&](int q) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     dv[u] = *(const f32x4*)(dr + q + 4 * u);
                     lv[u] = *(const f32x4*)(lm + q + 4 * u);
                 }
+            };
+            auto sum_up = [&]() {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     a0 = fmaf(dv[u][0], lv[u][0], a0);
@@ -410,11 +425,17 @@ __global__ __launch_bounds__(32 * kFB, 2) void cepstra_wide_kernel(
                     a2 = fmaf(dv[u][2], lv[u][2], a2);
                     a3 = fmaf(dv[u][3], lv[u][3], a3);
                 }
+            };
+#pragma unroll 1
+            for (int q = 0; q < cnt; q += 32) {
+                request(q);
+                sum_up();
             }
             float acc = (a0 + a1) + (a2 + a3);
-            if (parts == 2) acc += __shfl_xor(acc, 1, kWave);
+            if (PARTS == 2) acc += __shfl_xor(acc, 1, kWave);
             if (have && k < c.n_ceps && part == 0) cep[row * c.n_ceps + k] = acc;
         }
+        head(m_n, xc, m_nn, z1);
         wave_sync();
     };
     float x[2 * kP];
@@ -422,9 +443,12 @@ __global__ __launch_bounds__(32 * kFB, 2) void cepstra_wide_kernel(
     for (int i = 0; i < 2 * kP; ++i) x[i] = 0.f;
     int4 m0 = load_meta(b_begin), m1 = load_meta(b_begin + 1);
     fetch(m0, x);
+    cf z1[kP];
+    head(m0, x, b_begin + 1 < b_end ? m1 : m0, z1);
     for (int64_t b = b_begin; b < b_end; ++b) {
-        const int4 m2 = load_meta(b + 2);
-        transform(m0, row_of(b), x, b + 1 < b_end ? m1 : m0);   // (the last step's repeat is harmless)
+        // (past the range's end the last step is repeated: harmless, nothing of it is stored)
+        const int4 m2 = b + 2 < b_end ? load_meta(b + 2) : (b + 1 < b_end ? m1 : m0);
+        transform(m0, row_of(b), z1, x, b + 1 < b_end ? m1 : m0, m2);
         m0 = m1;
         m1 = m2;
     }
@@ -463,7 +487,9 @@ int srx_mfcc_wide_cepstra(srx_context* h, srx_mfcc_plan* p, const float* audio, 
                        4 * (size_t)kPerFrame * kFB + (c.n_ceps <= kDctLdsRows ? 4 * (size_t)c.n_ceps * kDctStride : 0);
     static_assert(kPwPad + kMaxParts + kMelPad <= kPerFrame,
                   "the partial mel sums and the log-mel row must fit the frame's tile");
-    auto kern = c.center == 2 ? cepstra_wide_kernel<cf, 2> : cepstra_wide_kernel<cf, 1>;
+    const bool two = c.n_ceps <= 16;
+    auto kern = c.center == 2 ? (two ? cepstra_wide_kernel<2, 2> : cepstra_wide_kernel<2, 1>)
+                              : (two ? cepstra_wide_kernel<1, 2> : cepstra_wide_kernel<1, 1>);
     SRX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t n_rows = v_total / c.hop + 1;
     // [n_rows] records, then [n_rows] row maxima and [n_rows] row minima
