@@ -240,6 +240,9 @@ __global__ __launch_bounds__(1024) void viterbi_fused_kernel(
             issue(i + 7, x3);
         }
         wave_sync();
+        // (the recursion is a chain of dependent steps, the emission above it bulk work: the wave
+        // inside its chain issues first; 0.487 -> 0.471 ms per 13.1 M frames on one box)
+        __builtin_amdgcn_s_setprio(2);
         const float* rows = tile + v * kTileStride + j;
 #pragma unroll
         for (int t4 = 0; t4 < 16; t4 += 4) {
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(1024) void viterbi_fused_kernel(
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         wave_sync();
     }
 
