@@ -446,7 +446,7 @@ def main():
                          "ms": dtf * 1e3,
                          "hbm_frac": raw_frames * 796 / dtf / 1e9 / HBM_PEAK_GBS,
                          "bound": "vector ALU issue (749 vector + 108 LDS + 44 matrix instructions per wave-step of "
-                                  "4 frames; the three waves of a SIMD keep its vector pipe busy 0.90 of the kernel's "
+                                  "4 frames; the three waves of a SIMD keep its vector pipe busy 0.87-0.90 of the kernel's "
                                   "time by the shader counters); HBM line shown for reference",
                          "flop_per_frame_executed": flop_per_frame,
                          "vector_peak_frac": raw_frames * flop_per_frame / dtf / 157.3e12,
