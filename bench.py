@@ -519,7 +519,32 @@ def main():
                                  "config": "librosa.feature.mfcc conventions: 22.05 kHz, centred 2048-pt frames "
                                            "every 512 samples, Hann, 128 Slaney mel, 10 log10, top_db 80, 13 MFCC, "
                                            "z-score (2048-point transform in registers, 32 lanes per frame)"}
-        del feats_l
+        # the chain recognize_lib runs per file (HMM_lib.py:11-15, :33, :85-97), for all recordings
+        # at once and with nothing leaving the device: audio -> 13 librosa-convention cepstra,
+        # z-scored -> scores against 6 word models of 3 states (GaussianHMM(n_components=3)) -> label
+        rng_l = np.random.default_rng(5)
+        bank_l = sra.HMMBank(ctx, rng_l.dirichlet(np.ones(3), size=N_MODELS),
+                             rng_l.dirichlet(np.ones(3), size=(N_MODELS, 3)),
+                             rng_l.standard_normal((N_MODELS, 3, 13)), rng_l.uniform(0.5, 1.5, (N_MODELS, 3, 13)))
+        data_l = plan_l.run_ragged(audio, so)
+        lab_l, sc_l = bank_l.classify(data_l)
+
+        def chain_l():
+            d = plan_l.run_ragged(audio, so, out=data_l.X)
+            return bank_l.classify(d, scores=sc_l, labels=lab_l)
+
+        warm_gpu(chain_l)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            chain_l()
+        barrier()
+        dtc = (time.perf_counter() - t0) / reps
+        extra["pipeline_librosa"] = {
+            "utterances_per_s": n_utt_fe * world / dtc, "frames_per_s": lib_frames * world / dtc, "ms": dtc * 1e3,
+            "config": f"{n_utt_fe} recordings x {n_samp} samples read as 22.05 kHz (float32, resident) -> 13 "
+                      "librosa-convention MFCC, z-score -> 6 x 3-state scores -> int32 label"}
+        del feats_l, data_l, lab_l, sc_l, bank_l
         # end-pointing pre-pass over the same recordings (10 ms block energies and
         # zero crossings, thresholds, run search)
         # (the offsets of the batch layout go to the device once, like the front-end's)
